@@ -1,0 +1,440 @@
+"""Deterministic synthetic workloads for the EKF/EKS hot path.
+
+The Oxford time-series the reference's drivers read are not in the checkout, so
+the benchmark/parity inputs are synthesised from the 235 trained parameter sets
+the reference does ship (epidemicmodeling_amd/data/trained_params_nonnegls.npz,
+extracted by tools/make_param_fixture.py) following the parameterisation of the
+reference's callers:
+
+  cfg3  SIAlphaModelEKF            Tools/TrainPredictPrescribeNPI.m:199-248,295-307
+  cfg4  SIAlphaModelEKFOptControlled sweep   Tools/TrainPredictPrescribeNPI.m:421-460,
+        epsilon grid testScripts/testPrescribeXPRIZE02.m:49-53
+  cfg5  3-state Monte-Carlo EKS    (process-noise draws, :229-231,497-521)
+
+Everything here is host-side NumPy input preparation; no filter arithmetic.
+All arrays come back in the batched SoA layout of include/epiekf.h.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import layout as L
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "trained_params_nonnegls.npz")
+
+IP_MAXES = np.array([3, 3, 2, 4, 2, 3, 2, 4, 2, 3, 2, 4], dtype=np.float64)  # testPrescribeXPRIZE02.m:38
+IP_MINS = np.zeros(12)                                                        # :37
+NUM_NPI = 12
+
+# constants of TrainPredictPrescribeNPI.m:12-22,202-227
+MIN_CASES = 1.0
+MODEL_GAMMA = 1.0 / 7.0
+MODEL_BETA = -np.log(0.01) / 21.0
+ALPHA0 = MODEL_BETA + np.log(2.5)
+ALPHA_MIN, ALPHA_MAX = 1e-8, 100.0
+SIGMA = 1e6
+BETA_EKF, GAMMA_EKF, MONITOR_LEN = 1.0, 0.995, 21
+Q_LAMBDA = 1e-4
+
+
+@dataclass
+class Workload:
+    """One batched filter problem in ABI layout (all float64, C-contiguous)."""
+    model: str
+    T: int
+    n_npi: int
+    x: np.ndarray                 # [T, Sx]
+    u: np.ndarray                 # [T, n_npi, Su]
+    R_series: np.ndarray | None   # [T, Sx]
+    R_scalar: np.ndarray | None   # [B]
+    x_series: np.ndarray | None   # [B] int32: column of x / R_series each chain reads (None = identity)
+    u_series: np.ndarray | None   # [B] int32: column of u each chain reads (None = identity)
+    prm: np.ndarray               # [EPI_PRM_COUNT, B]
+    s_init: np.ndarray            # [m, B]
+    Ps_init: np.ndarray           # [m*m, B]
+    s_final: np.ndarray           # [m, B]
+    Ps_final: np.ndarray          # [m*m, B]
+    Q: np.ndarray                 # [m*m, B]
+    L: int = MONITOR_LEN
+    order: int = 1
+    obs_type: str = "NEWCASES"
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def B(self) -> int:
+        return self.prm.shape[1]
+
+    @property
+    def Sx(self) -> int:
+        return self.x.shape[1]
+
+    @property
+    def Su(self) -> int:
+        return self.u.shape[2]
+
+    @property
+    def m(self) -> int:
+        return L.MODEL_DIM[self.model]
+
+    def select(self, chains) -> "Workload":
+        """Sub-batch of the given chain indices (series are kept whole and re-indexed)."""
+        chains = np.asarray(chains, dtype=np.int64)
+        xs = self.x_series[chains] if self.x_series is not None else chains
+        us = self.u_series[chains] if self.u_series is not None else chains
+        xused, xinv = np.unique(xs, return_inverse=True)
+        uused, uinv = np.unique(us, return_inverse=True)
+        return Workload(
+            model=self.model, T=self.T, n_npi=self.n_npi,
+            x=np.ascontiguousarray(self.x[:, xused]), u=np.ascontiguousarray(self.u[:, :, uused]),
+            R_series=None if self.R_series is None else np.ascontiguousarray(self.R_series[:, xused]),
+            R_scalar=None if self.R_scalar is None else np.ascontiguousarray(self.R_scalar[chains]),
+            x_series=xinv.astype(np.int32), u_series=uinv.astype(np.int32),
+            prm=np.ascontiguousarray(self.prm[:, chains]),
+            s_init=np.ascontiguousarray(self.s_init[:, chains]),
+            Ps_init=np.ascontiguousarray(self.Ps_init[:, chains]),
+            s_final=np.ascontiguousarray(self.s_final[:, chains]),
+            Ps_final=np.ascontiguousarray(self.Ps_final[:, chains]),
+            Q=np.ascontiguousarray(self.Q[:, chains]),
+            L=self.L, order=self.order, obs_type=self.obs_type, meta=dict(self.meta))
+
+
+def load_trained_params():
+    d = np.load(_DATA)
+    return {k: d[k] for k in d.files}
+
+
+def make_regions(n_regions: int, seed: int = 20210207):
+    """Regions r -> row r mod 235 of the trained-parameter table; wrapped rows get `a`
+    jittered by 1 + 0.1*U(-1,1) (Philox stream `seed`)."""
+    tp = load_trained_params()
+    n_real = tp["N_population"].shape[0]
+    idx = np.arange(n_regions) % n_real
+    N = tp["N_population"][idx].astype(np.float64)
+    a = tp["coef_2"][idx].astype(np.float64).copy()
+    b = tp["coef0_2"][idx].astype(np.float64).copy()
+    rng = np.random.Generator(np.random.Philox(seed))
+    jit = 1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=(n_regions, NUM_NPI))
+    wrapped = np.arange(n_regions) >= n_real
+    a[wrapped] *= jit[wrapped]
+    return {"N": N, "a": a, "b": b, "names": tp["names"][idx]}
+
+
+def make_npi_history(n_regions: int, T: int, seed: int = 1, p_switch: float = 0.02):
+    """Piecewise-constant integer NPI paths in [0, IP_MAXES]; returns [T, 12, n_regions]."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    u = np.zeros((T, NUM_NPI, n_regions))
+    cur = rng.integers(0, IP_MAXES.astype(np.int64)[:, None] + 1, size=(NUM_NPI, n_regions))
+    for t in range(T):
+        sw = rng.random((NUM_NPI, n_regions)) < p_switch
+        new = rng.integers(0, IP_MAXES.astype(np.int64)[:, None] + 1, size=(NUM_NPI, n_regions))
+        cur = np.where(sw, new, cur)
+        u[t] = cur
+    return u
+
+
+def _causal_ma(x, n):
+    """filter(ones(1,n), n, x) along axis 0 (zero initial conditions)."""
+    c = np.cumsum(x, axis=0)
+    out = c.copy()
+    out[n:] = c[n:] - c[:-n]
+    return out / n
+
+
+def _zero_lag_ma(x, n):
+    """Forward-backward moving average (stands in for MATLAB filtfilt(ones(1,n), n, x);
+    edge handling by odd reflection of 3*(n-1) samples like filtfilt)."""
+    pad = 3 * (n - 1)
+    lo = 2 * x[0] - x[pad:0:-1]
+    hi = 2 * x[-1] - x[-2:-pad - 2:-1]
+    y = np.concatenate([lo, x, hi], axis=0)
+    y = _causal_ma(y, n)
+    y = _causal_ma(y[::-1], n)[::-1]
+    return y[pad:pad + x.shape[0]]
+
+
+def simulate_observations(regions, u_hist, seed: int = 2):
+    """SIalpha_Controlled.m semantics (noise-free), daily counts Poisson-thinned, then the
+    reference's preprocessing (TrainPredictPrescribeNPI.m:173-175,240).
+    Returns dict with x [T,R] (normalised smoothed new cases), R_v [T,R], I0 [R]."""
+    T, _, nR = u_hist.shape
+    N, a, b = regions["N"], regions["a"], regions["b"]
+    s = 1.0 - 100.0 / N
+    i = 100.0 / N
+    al = np.full(nR, ALPHA0)
+    lam = np.zeros((T, nR))
+    truth = np.zeros((T, 3, nR))
+    dt = 1.0
+    for t in range(T):
+        drive = np.einsum("rk,kr->r", MODEL_GAMMA * a, IP_MAXES[:, None] - u_hist[t])
+        sn = np.maximum(0.0, np.minimum(1.0, s - dt * (al * s * i)))
+        inn = np.maximum(0.0, np.minimum(1.0, i + dt * (al * s * i - MODEL_BETA * i)))
+        an = np.maximum(ALPHA_MIN, np.minimum(ALPHA_MAX, al + dt * (-MODEL_GAMMA * al + MODEL_GAMMA * b + drive)))
+        s, i, al = sn, inn, an
+        lam[t] = N * s * i * al
+        truth[t, 0], truth[t, 1], truth[t, 2] = s, i, al
+    rng = np.random.Generator(np.random.Philox(seed))
+    raw = rng.poisson(np.minimum(lam, 1e15)).astype(np.float64)
+    smoothed = _causal_ma(raw, 7)
+    zero_lag = _zero_lag_ma(raw, 4)
+    x = smoothed / N
+    R_v = 0.1 * ((zero_lag - raw) / N) ** 2
+    I0 = np.ones(nR)
+    for r in range(nR):
+        nz = np.flatnonzero(smoothed[:, r] > 0)[:7]
+        if nz.size:
+            I0[r] = max(MIN_CASES, float(np.mean(smoothed[nz, r])))
+    return {"x": x, "R_v": R_v, "I0": I0, "raw": raw, "truth": truth}
+
+
+def _base_prm(B):
+    prm = np.zeros((L.PRM_COUNT, B))
+    prm[L.PRM_DT] = 1.0
+    prm[L.PRM_BETA] = MODEL_BETA
+    prm[L.PRM_GAMMA] = MODEL_GAMMA
+    prm[L.PRM_SIGMA] = SIGMA
+    prm[L.PRM_EPSILON] = np.nan
+    prm[L.PRM_ALPHA_MIN] = ALPHA_MIN
+    prm[L.PRM_ALPHA_MAX] = ALPHA_MAX
+    prm[L.PRM_W_EFF:L.PRM_W_EFF + 12] = np.nan
+    prm[L.PRM_U_MIN:L.PRM_U_MIN + 12] = IP_MINS[:, None]
+    prm[L.PRM_U_MAX:L.PRM_U_MAX + 12] = IP_MAXES[:, None]
+    prm[L.PRM_V_BAR] = 0.0
+    prm[L.PRM_BETA_EKF] = BETA_EKF
+    prm[L.PRM_GAMMA_EKF] = GAMMA_EKF
+    return prm
+
+
+def _filter_setup3(regions, I0):
+    """s_init, Q_w, Ps_init of TrainPredictPrescribeNPI.m:229-237 per region -> ([3,R],[9,R],[9,R])."""
+    N = regions["N"]
+    nR = N.shape[0]
+    s_std = 10.0 * I0 / N
+    i_std = 30.0 * I0 / N
+    a_std = np.full(nR, 1e-2)
+    stds = np.stack([s_std, i_std, a_std])
+    Q = np.zeros((9, nR)); P0 = np.zeros((9, nR))
+    for d in range(3):
+        Q[d * 3 + d] = stds[d] ** 2
+        P0[d * 3 + d] = (10.0 * stds[d]) ** 2
+    s_init = np.stack([(N - I0) / N, I0 / N, np.full(nR, ALPHA0)])
+    return s_init, Q, P0
+
+
+def make_cfg3(n_regions: int = 300, T: int = 400) -> Workload:
+    """BASELINE config 3: SIAlphaModelEKF over `n_regions` regions x T days (round-2 call:
+    a, b from the trained table, u = NPI history, R_v 1xT)."""
+    reg = make_regions(n_regions)
+    u = make_npi_history(n_regions, T)
+    obs = simulate_observations(reg, u)
+    s_init, Q, P0 = _filter_setup3(reg, obs["I0"])
+    prm = _base_prm(n_regions)
+    prm[L.PRM_S_MIN] = MIN_CASES / reg["N"]
+    prm[L.PRM_I_MIN] = MIN_CASES / reg["N"]
+    prm[L.PRM_B] = reg["b"]
+    prm[L.PRM_A:L.PRM_A + 12] = reg["a"].T
+    return Workload(model="SIAlphaModelEKF", T=T, n_npi=NUM_NPI, x=np.ascontiguousarray(obs["x"]),
+                    u=np.ascontiguousarray(u), R_series=np.ascontiguousarray(obs["R_v"]), R_scalar=None,
+                    x_series=None, u_series=None, prm=prm, s_init=s_init, Ps_init=P0,
+                    s_final=np.full((3, n_regions), np.nan), Ps_final=np.full((9, n_regions), np.nan), Q=Q,
+                    meta={"workload": "cfg3", "regions": n_regions, "truth_end": obs["truth"][-1]})
+
+
+def epsilon_grid(n: int = 250) -> np.ndarray:
+    """human_npi_cost_factor of testPrescribeXPRIZE02.m:52-53."""
+    eps = np.finfo(np.float64).eps
+    h = n // 2
+    return np.concatenate([np.logspace(-12.0, -eps, h), np.linspace(eps, 1 - eps, n - h)])
+
+
+def make_cfg4(n_regions: int = 300, n_eps: int = 250, T_hist: int = 400, horizon: int = 120) -> Workload:
+    """BASELINE config 4: SIAlphaModelEKFOptControlled Pareto sweep, regions x epsilon chains over
+    T_hist observed days + `horizon` days with x = NaN and u = NaN (TrainPredictPrescribeNPI.m:421-460).
+    Chain c = r * n_eps + e shares region r's series."""
+    reg = make_regions(n_regions)
+    u_hist = make_npi_history(n_regions, T_hist)
+    obs = simulate_observations(reg, u_hist)
+    T = T_hist + horizon
+    x = np.concatenate([obs["x"], np.full((horizon, n_regions), np.nan)], axis=0)
+    u = np.concatenate([u_hist, np.full((horizon, NUM_NPI, n_regions), np.nan)], axis=0)
+    Rv = np.concatenate([obs["R_v"], np.ones((horizon, 1)) * obs["R_v"].mean(axis=0, keepdims=True)], axis=0)
+    s3, Q3, P3 = _filter_setup3(reg, obs["I0"])
+    B = n_regions * n_eps
+    rr = np.repeat(np.arange(n_regions), n_eps)
+    eps_grid = epsilon_grid(n_eps)
+    prm = _base_prm(B)
+    prm[L.PRM_S_MIN] = (MIN_CASES / reg["N"])[rr]
+    prm[L.PRM_I_MIN] = (MIN_CASES / reg["N"])[rr]
+    prm[L.PRM_B] = reg["b"][rr]
+    prm[L.PRM_A:L.PRM_A + 12] = reg["a"].T[:, rr]
+    prm[L.PRM_EPSILON] = np.tile(eps_grid, n_regions)
+    # npi_weights = ones(1,12) is a ROW vector => phi(kk) uses w(1) for every NPI
+    prm[L.PRM_W_EFF:L.PRM_W_EFF + 12] = 1.0
+    s_init = np.zeros((6, B)); s_init[:3] = s3[:, rr]
+    Q = np.zeros((36, B)); P0 = np.zeros((36, B))
+    for d in range(3):
+        Q[d * 6 + d] = Q3[d * 3 + d][rr]
+        P0[d * 6 + d] = P3[d * 3 + d][rr]
+    for d in range(3, 6):
+        Q[d * 6 + d] = Q_LAMBDA ** 2
+        P0[d * 6 + d] = 10.0 * Q_LAMBDA ** 2
+    s_final = np.full((6, B), np.nan); s_final[3:] = 0.0
+    Ps_final = np.zeros((36, B))
+    for i in range(3):
+        for j in range(3):
+            Ps_final[i + 6 * j] = np.nan
+    for d in range(3, 6):
+        Ps_final[d * 6 + d] = 1e-8
+    return Workload(model="SIAlphaModelEKFOptControlled", T=T, n_npi=NUM_NPI, x=np.ascontiguousarray(x),
+                    u=np.ascontiguousarray(u), R_series=np.ascontiguousarray(Rv), R_scalar=None,
+                    x_series=rr.astype(np.int32), u_series=rr.astype(np.int32), prm=prm, s_init=s_init, Ps_init=P0,
+                    s_final=s_final, Ps_final=Ps_final, Q=Q,
+                    meta={"workload": "cfg4", "regions": n_regions, "n_eps": n_eps, "T_hist": T_hist,
+                          "horizon": horizon, "truth_end": obs["truth"][-1][:, rr]})
+
+
+def make_cfg5(n_regions: int = 300, n_draws: int = 1024, T: int = 400, seed: int = 5) -> Workload:
+    """BASELINE config 5: 3-state Monte-Carlo EKS -- every chain filters its own noisy realisation
+    of the region's epidemic (process-noise draws with the stds of :229-231), so S == B."""
+    reg = make_regions(n_regions)
+    u_hist = make_npi_history(n_regions, T)
+    base = simulate_observations(reg, u_hist)
+    B = n_regions * n_draws
+    rr = np.repeat(np.arange(n_regions), n_draws)
+    rng = np.random.Generator(np.random.Philox(seed))
+    N = reg["N"][rr]
+    # multiplicative observation jitter + additive noise at the level of the region's R_v
+    noise = rng.standard_normal((T, B)) * np.sqrt(base["R_v"][:, rr] + (0.05 * base["x"][:, rr]) ** 2)
+    x = np.maximum(0.0, base["x"][:, rr] + noise)
+    s3, Q3, P3 = _filter_setup3(reg, base["I0"])
+    prm = _base_prm(B)
+    prm[L.PRM_S_MIN] = MIN_CASES / N
+    prm[L.PRM_I_MIN] = MIN_CASES / N
+    prm[L.PRM_B] = reg["b"][rr]
+    prm[L.PRM_A:L.PRM_A + 12] = reg["a"].T[:, rr]
+    return Workload(model="SIAlphaModelEKF", T=T, n_npi=NUM_NPI, x=np.ascontiguousarray(x),
+                    u=np.ascontiguousarray(u_hist), R_series=np.ascontiguousarray(base["R_v"][:, rr]),
+                    R_scalar=None, x_series=None, u_series=rr.astype(np.int32), prm=prm, s_init=s3[:, rr], Ps_init=P3[:, rr],
+                    s_final=np.full((3, B), np.nan), Ps_final=np.full((9, B), np.nan), Q=Q3[:, rr],
+                    meta={"workload": "cfg5", "regions": n_regions, "draws": n_draws})
+
+
+def _sim_sialpha(N, a, b, u, s0, i0, al0, alpha_min, alpha_max, gamma, beta, stds, z):
+    """Vectorised SIalpha_Controlled.m over regions: u [K,12,R], z [K,3,R] -> s,i,alpha [K,R]."""
+    K = u.shape[0]
+    s, i, al = s0.copy(), i0.copy(), al0.copy()
+    S = np.zeros((K, N.shape[0])); I = np.zeros_like(S); A = np.zeros_like(S)
+    for t in range(K):
+        drive = np.einsum("rk,kr->r", gamma * a, IP_MAXES[:, None] - u[t])
+        sn = np.maximum(0.0, np.minimum(1.0, s - (al * s * i + z[t, 0] * stds[0])))
+        inn = np.maximum(0.0, np.minimum(1.0, i + (al * s * i - beta * i + z[t, 1] * stds[1])))
+        an = np.maximum(alpha_min, np.minimum(alpha_max, al + (-gamma * al + gamma * b + drive + z[t, 2] * stds[2])))
+        s, i, al = sn, inn, an
+        S[t], I[t], A[t] = s, i, al
+    return S, I, A
+
+
+def make_row3(n_regions: int = 4, n_eps: int = 6, T_hist: int = 30, horizon: int = 120, seed: int = 3) -> Workload:
+    """testScripts/testPrescribeXPRIZE01.m:76-211 parameterisation: fully synthetic 6-state sweep with a
+    scalar R_v = var(scalar) = 0 adapted by beta_ekf = 0.9, observations present on all days, 12 x D
+    random weights (=> w_eff = first day's column), alpha_max = inf, sigma = 1e4."""
+    reg = make_regions(n_regions)
+    N, a, b = reg["N"], reg["a"], reg["b"]
+    T = T_hist + horizon
+    rng = np.random.Generator(np.random.Philox(seed))
+    I0 = 10.0
+    i0 = I0 / N; s0 = (N - I0) / N
+    u_sim = np.zeros((T, NUM_NPI, n_regions))
+    z = rng.standard_normal((T, 3, n_regions))
+    S, I, A = _sim_sialpha(N, a, b, u_sim, s0, i0, np.full(n_regions, ALPHA0), 0.0, 1.0, MODEL_GAMMA, MODEL_BETA,
+                           (1e-8, 1e-8, 1e-9), z)
+    x = S * I * A
+    u = np.concatenate([np.zeros((T_hist, NUM_NPI, n_regions)), np.full((horizon, NUM_NPI, n_regions), np.nan)])
+    w_day = rng.random((NUM_NPI, T))
+    h = n_eps // 2
+    eps_grid = np.concatenate([np.logspace(-9.0, 0.0, h), np.linspace(0.0, 1.0, n_eps - h)])
+    B = n_regions * n_eps
+    rr = np.repeat(np.arange(n_regions), n_eps)
+    prm = _base_prm(B)
+    prm[L.PRM_SIGMA] = 1e4
+    prm[L.PRM_ALPHA_MIN] = 0.0
+    prm[L.PRM_ALPHA_MAX] = np.inf
+    prm[L.PRM_B] = b[rr]
+    prm[L.PRM_A:L.PRM_A + 12] = a.T[:, rr]
+    prm[L.PRM_EPSILON] = np.tile(eps_grid, n_regions)
+    prm[L.PRM_W_EFF:L.PRM_W_EFF + 12] = w_day[:, :1]            # w is 12 x D => phi(kk) uses w(kk, 1)
+    prm[L.PRM_BETA_EKF] = 0.9
+    q_alpha, q_lambda = 1e-2, 10.0
+    s_init = np.stack([s0[rr], i0[rr], np.full(B, ALPHA0), np.ones(B), np.ones(B), np.ones(B)])
+    qd = np.stack([10.0 * i0[rr], 30.0 * i0[rr], np.full(B, q_alpha), np.full(B, q_lambda), np.full(B, q_lambda),
+                   np.full(B, q_lambda)]) ** 2
+    pd = 100.0 * np.stack([i0[rr], i0[rr], np.full(B, q_alpha), np.full(B, q_lambda), np.full(B, q_lambda),
+                           np.full(B, q_lambda)]) ** 2
+    Q = np.zeros((36, B)); P0 = np.zeros((36, B))
+    for d in range(6):
+        Q[d * 6 + d] = qd[d]; P0[d * 6 + d] = pd[d]
+    s_final = np.full((6, B), np.nan); s_final[3:] = 0.0
+    Ps_final = np.zeros((36, B))
+    for i in range(3):
+        for j in range(3):
+            Ps_final[i + 6 * j] = np.nan
+    for d in range(3, 6):
+        Ps_final[d * 6 + d] = 1e-3
+    return Workload(model="SIAlphaModelEKFOptControlled", T=T, n_npi=NUM_NPI, x=np.ascontiguousarray(x),
+                    u=np.ascontiguousarray(u), R_series=None, R_scalar=np.zeros(B),
+                    x_series=rr.astype(np.int32), u_series=rr.astype(np.int32), prm=prm, s_init=s_init,
+                    Ps_init=P0, s_final=s_final, Ps_final=Ps_final, Q=Q,
+                    meta={"workload": "row3", "regions": n_regions, "n_eps": n_eps})
+
+
+def make_row4(n_regions: int = 4, T: int = 200, predict_ahead: int = 90, codegen: bool = False, seed: int = 4) -> Workload:
+    """testScripts/testSIModelOptimalControl04EKS.m:140-168,282-302 parameterisation of
+    NewCaseEKFEstimatorWithOptimalNPI: gamma = 1/100, beta = 1/75, sigma = 1e5, epsilon = 1e-3, scalar
+    R_v = 1e-6 adapted with beta_ekf = 0.9, all-NaN end points, last `predict_ahead` days u = NaN."""
+    reg = make_regions(n_regions)
+    N, a, b = reg["N"], reg["a"], reg["b"]
+    u_hist = make_npi_history(n_regions, T, seed=seed)
+    obs = simulate_observations(reg, u_hist, seed=seed + 100)
+    u = u_hist.copy()
+    u[T - predict_ahead:] = np.nan
+    I0 = np.maximum(1.0, obs["x"][0] * N)
+    B = n_regions
+    prm = _base_prm(B)
+    prm[L.PRM_GAMMA] = 1.0 / 100.0
+    prm[L.PRM_BETA] = 1.0 / 75.0
+    prm[L.PRM_SIGMA] = 1e5
+    prm[L.PRM_EPSILON] = 1e-3
+    prm[L.PRM_ALPHA_MIN] = 0.0
+    prm[L.PRM_ALPHA_MAX] = np.inf
+    prm[L.PRM_B] = b
+    prm[L.PRM_A:L.PRM_A + 12] = a.T
+    prm[L.PRM_W_EFF:L.PRM_W_EFF + 12] = 1.0
+    prm[L.PRM_BETA_EKF] = 0.9
+    qd = np.array([0.01, 0.01, 0.1, 10.0, 10.0, 10.0]) ** 2
+    Q = np.zeros((36, B)); P0 = np.zeros((36, B))
+    for d in range(6):
+        Q[d * 6 + d] = qd[d]; P0[d * 6 + d] = 1000.0 * qd[d]
+    s_init = np.stack([(N - I0) / N, I0 / N, np.full(B, 0.01), np.ones(B), np.ones(B), np.ones(B)])
+    name = "NewCaseEKFEstimatorWithOptimalNPI" + ("_codegen" if codegen else "")
+    return Workload(model=name, T=T, n_npi=NUM_NPI, x=np.ascontiguousarray(obs["x"]), u=np.ascontiguousarray(u),
+                    R_series=None, R_scalar=np.full(B, 1e-6), x_series=None, u_series=None, prm=prm,
+                    s_init=s_init, Ps_init=P0, s_final=np.full((6, B), np.nan),
+                    Ps_final=np.full((36, B), np.nan), Q=Q, meta={"workload": "row4", "regions": n_regions})
+
+
+def as_backward(w: Workload) -> Workload:
+    """The same inputs routed to the time-flipped wrapper (SIAlphaModelBackwardEKF[OptControlled]).
+    The wrapper starts the flipped filter from (s_final, Ps_final), so those must be finite: the
+    simulated end state of the epidemic (costates 0) with the forward initial covariance, the way the
+    reference's commented-out drivers seed it (TrainPredictPrescribeNPI.m:466-468); s_init / Ps_init
+    become the flipped smoother's end-point constraints."""
+    name = {"SIAlphaModelEKF": "SIAlphaModelBackwardEKF",
+            "SIAlphaModelEKFOptControlled": "SIAlphaModelBackwardEKFOptControlled"}[w.model]
+    out = w.select(np.arange(w.B))
+    out.model = name
+    out.s_final = np.zeros_like(w.s_init)
+    out.s_final[:3] = w.meta["truth_end"]
+    out.Ps_final = w.Ps_init.copy()
+    return out

@@ -1,0 +1,880 @@
+/*
+ * ekf_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.  "parity unpinned"
+ * by the reference's own tests (see ekf_oracle.h for how it is pinned instead).
+ *
+ * CPU restatement (plain C, IEEE fp64, no FMA contraction: build with
+ * -ffp-contract=off) of
+ *   Tools/GenericExtendedKalmanFilter.m            (whole file)
+ *   Tools/SIAlphaModelEKF.m:27-109                 (3-state callbacks)
+ *   Tools/SIAlphaModelEKFOptControlled.m:27-168    (6-state callbacks)
+ *   Tools/SIAlphaModelBackwardEKF.m:19-130         (flipped 3-state)
+ *   Tools/SIAlphaModelBackwardEKFOptControlled.m:19-189 (flipped 6-state)
+ *   Tools/NewCaseEKFEstimatorWithOptimalNPI.m:1-290 (+ MatlabCodeGenerator twin)
+ *   Tools/SIalpha_Controlled.m, SI_Controlled.m, SEIRP.m,
+ *   Tools/SEIRPSaturatedResource.m, Tools/NPICost.m
+ * MATLAB built-ins restated: pinv (symmetric argument: cyclic Jacobi
+ * eigen-decomposition + tol = max(size)*eps(norm)), mrdivide for a square
+ * right operand (LU with partial pivoting, LAPACK dgetf2/dgetrs operation
+ * order), NaN-ignoring min/max (fmin/fmax), eps, squeeze.
+ *
+ * Matrix products are evaluated as MATLAB writes them, left to right, each
+ * product as  C(i,j) = sum_k A(i,k)*B(k,j)  with k ascending and the first
+ * term taken as is (no leading 0 +).
+ */
+#include "ekf_oracle.h"
+#include "../include/epiekf_layout.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MM 6            /* max state dimension */
+#define DBL_EPS 2.220446049250313e-16 /* MATLAB eps */
+
+/* ---------- small dense helpers (column-major, leading dimension m) ---------- */
+#define IX(i, j, m) ((i) + (m) * (j))
+
+static void mat_mul(int m, const double *A, const double *B, double *C) /* C = A*B */
+{
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) {
+            double acc = A[IX(i, 0, m)] * B[IX(0, j, m)];
+            for (int k = 1; k < m; k++) acc = acc + A[IX(i, k, m)] * B[IX(k, j, m)];
+            C[IX(i, j, m)] = acc;
+        }
+}
+static void mat_mul_bt(int m, const double *A, const double *B, double *C) /* C = A*B' */
+{
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) {
+            double acc = A[IX(i, 0, m)] * B[IX(j, 0, m)];
+            for (int k = 1; k < m; k++) acc = acc + A[IX(i, k, m)] * B[IX(j, k, m)];
+            C[IX(i, j, m)] = acc;
+        }
+}
+static void symmetrize(int m, double *P) /* P = (P + P')/2.0 */
+{
+    for (int j = 0; j < m; j++)
+        for (int i = j + 1; i < m; i++) {
+            double v = (P[IX(i, j, m)] + P[IX(j, i, m)]) / 2.0;
+            double w = (P[IX(j, i, m)] + P[IX(i, j, m)]) / 2.0; /* commutative: v == w */
+            P[IX(i, j, m)] = v;
+            P[IX(j, i, m)] = w;
+        }
+    for (int i = 0; i < m; i++) P[IX(i, i, m)] = (P[IX(i, i, m)] + P[IX(i, i, m)]) / 2.0;
+}
+
+/* ---------- MATLAB pinv for a symmetric argument ----------
+ * pinv(A): [U,S,V]=svd(A); tol = max(size(A))*eps(norm(s,inf)); keep s>tol;
+ * X = V(:,keep)*diag(1./s(keep))*U(:,keep)'.  For symmetric A the singular
+ * triplets are (|lambda_i|, sign(lambda_i) v_i, v_i).  The eigen-decomposition is
+ * the cyclic Jacobi method (Rutishauser / Numerical-Recipes formulation with the
+ * b/z accumulators), run on A scaled by an exact power of two.  The kept terms
+ * are accumulated in the eigenvalue index order the iteration leaves them in. */
+static double eps_of(double x) /* MATLAB eps(x) for finite x >= 0 */
+{
+    if (x == 0.0) return 4.9406564584124654e-324;
+    int e = ilogb(x);
+    if (e < -1022) return 4.9406564584124654e-324;
+    return ldexp(1.0, e - 52);
+}
+
+#define ORC_JACOBI_MAX_SWEEPS 50
+
+static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double *d, double *v)
+{
+    double b[MM], z[MM];
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) v[IX(i, j, m)] = (i == j) ? 1.0 : 0.0;
+    for (int i = 0; i < m; i++) {
+        b[i] = d[i] = a[IX(i, i, m)];
+        z[i] = 0.0;
+    }
+    for (int sweep = 1; sweep <= ORC_JACOBI_MAX_SWEEPS; sweep++) {
+        double sm = 0.0;
+        for (int p = 0; p < m - 1; p++)
+            for (int q = p + 1; q < m; q++) sm = sm + fabs(a[IX(p, q, m)]);
+        if (sm == 0.0) break;
+        double tresh = (sweep < 4) ? 0.2 * sm / (double)(m * m) : 0.0;
+        for (int p = 0; p < m - 1; p++)
+            for (int q = p + 1; q < m; q++) {
+                double apq = a[IX(p, q, m)];
+                double g = 100.0 * fabs(apq);
+                if (sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q])) {
+                    a[IX(p, q, m)] = 0.0;
+                } else if (fabs(apq) > tresh) {
+                    double h = d[q] - d[p];
+                    double t;
+                    if ((fabs(h) + g) == fabs(h)) {
+                        t = apq / h;
+                    } else {
+                        double theta = 0.5 * h / apq;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    double c = 1.0 / sqrt(1.0 + t * t);
+                    double s = t * c;
+                    double tau = s / (1.0 + c);
+                    h = t * apq;
+                    z[p] = z[p] - h;
+                    z[q] = z[q] + h;
+                    d[p] = d[p] - h;
+                    d[q] = d[q] + h;
+                    a[IX(p, q, m)] = 0.0;
+#define ROT(x, y)                                  \
+    do {                                           \
+        double g_ = (x), h_ = (y);                 \
+        (x) = g_ - s * (h_ + g_ * tau);            \
+        (y) = h_ + s * (g_ - h_ * tau);            \
+    } while (0)
+                    for (int j = 0; j < p; j++) ROT(a[IX(j, p, m)], a[IX(j, q, m)]);
+                    for (int j = p + 1; j < q; j++) ROT(a[IX(p, j, m)], a[IX(j, q, m)]);
+                    for (int j = q + 1; j < m; j++) ROT(a[IX(p, j, m)], a[IX(q, j, m)]);
+                    for (int j = 0; j < m; j++) ROT(v[IX(j, p, m)], v[IX(j, q, m)]);
+#undef ROT
+                }
+            }
+        for (int i = 0; i < m; i++) {
+            b[i] = b[i] + z[i];
+            d[i] = b[i];
+            z[i] = 0.0;
+        }
+    }
+}
+
+int orc_sym_pinv(int m, const double *A, double *X)
+{
+    double a[MM * MM], d[MM], v[MM * MM];
+    double amax = 0.0;
+    for (int i = 0; i < m * m; i++) amax = fmax(amax, fabs(A[i]));
+    for (int i = 0; i < m * m; i++) X[i] = 0.0;
+    if (amax == 0.0) return 0;
+    int e = ilogb(amax);
+    /* only the upper triangle (i<=j) is referenced, as the iteration does */
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) a[IX(i, j, m)] = ldexp(A[IX(i <= j ? i : j, i <= j ? j : i, m)], -e);
+    jacobi_eig(m, a, d, v);
+    double smax = 0.0;
+    for (int i = 0; i < m; i++) smax = fmax(smax, fabs(d[i]));
+    double tol = (double)m * eps_of(smax);
+    int rank = 0;
+    for (int i = 0; i < m; i++) {
+        double sv = fabs(d[i]);
+        if (!(sv > tol)) continue;
+        rank++;
+        double inv = 1.0 / sv;
+        double sg = (d[i] < 0.0) ? -1.0 : 1.0;
+        for (int c = 0; c < m; c++)
+            for (int r = 0; r < m; r++)
+                X[IX(r, c, m)] = X[IX(r, c, m)] + (v[IX(r, i, m)] * inv) * (sg * v[IX(c, i, m)]);
+    }
+    for (int i = 0; i < m * m; i++) X[i] = ldexp(X[i], -e);
+    return rank;
+}
+
+/* ---------- MATLAB mrdivide, square right operand: X = B/A = (A'\B')' ----------
+ * dgetf2 (unblocked right-looking LU, first-max partial pivoting, reciprocal
+ * scaling of the sub-column as in the reference LAPACK when |pivot| >= sfmin)
+ * followed by dgetrs (dlaswp, unit-lower dtrsm, upper dtrsm; reference-BLAS
+ * column-oriented operation order). */
+void orc_mrdivide(int m, const double *B, const double *A, double *X)
+{
+    double M[MM * MM], Y[MM * MM];
+    int piv[MM];
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) {
+            M[IX(i, j, m)] = A[IX(j, i, m)]; /* A' */
+            Y[IX(i, j, m)] = B[IX(j, i, m)]; /* B' */
+        }
+    for (int j = 0; j < m; j++) {
+        int p = j;
+        double best = fabs(M[IX(j, j, m)]);
+        for (int i = j + 1; i < m; i++) {
+            double v = fabs(M[IX(i, j, m)]);
+            if (v > best) { best = v; p = i; }
+        }
+        piv[j] = p;
+        if (M[IX(p, j, m)] != 0.0) {
+            if (p != j)
+                for (int c = 0; c < m; c++) {
+                    double t = M[IX(j, c, m)];
+                    M[IX(j, c, m)] = M[IX(p, c, m)];
+                    M[IX(p, c, m)] = t;
+                }
+            if (fabs(M[IX(j, j, m)]) >= 2.2250738585072014e-308) {
+                double r = 1.0 / M[IX(j, j, m)];
+                for (int i = j + 1; i < m; i++) M[IX(i, j, m)] = M[IX(i, j, m)] * r;
+            } else {
+                for (int i = j + 1; i < m; i++) M[IX(i, j, m)] = M[IX(i, j, m)] / M[IX(j, j, m)];
+            }
+        }
+        for (int c = j + 1; c < m; c++)
+            for (int i = j + 1; i < m; i++)
+                M[IX(i, c, m)] = M[IX(i, c, m)] - M[IX(i, j, m)] * M[IX(j, c, m)];
+    }
+    /* row interchanges on the right-hand sides */
+    for (int j = 0; j < m; j++)
+        if (piv[j] != j)
+            for (int c = 0; c < m; c++) {
+                double t = Y[IX(j, c, m)];
+                Y[IX(j, c, m)] = Y[IX(piv[j], c, m)];
+                Y[IX(piv[j], c, m)] = t;
+            }
+    for (int c = 0; c < m; c++) {
+        /* L y = b, unit diagonal */
+        for (int k = 0; k < m; k++)
+            if (Y[IX(k, c, m)] != 0.0)
+                for (int i = k + 1; i < m; i++)
+                    Y[IX(i, c, m)] = Y[IX(i, c, m)] - Y[IX(k, c, m)] * M[IX(i, k, m)];
+        /* U x = y */
+        for (int k = m - 1; k >= 0; k--)
+            if (Y[IX(k, c, m)] != 0.0) {
+                Y[IX(k, c, m)] = Y[IX(k, c, m)] / M[IX(k, k, m)];
+                for (int i = 0; i < k; i++)
+                    Y[IX(i, c, m)] = Y[IX(i, c, m)] - Y[IX(k, c, m)] * M[IX(i, k, m)];
+            }
+    }
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) X[IX(i, j, m)] = Y[IX(j, i, m)];
+}
+
+/* ---------- model callbacks ---------- */
+typedef struct model_ops {
+    int m;
+    int flipped;       /* sign of every dt term reversed */
+    int lo_is_zero;    /* s,i clamps use 0 instead of s_min/i_min */
+    int phi_ge;        /* bang-bang test phi >= 0 (NewCase...:175) instead of phi > 0 */
+    int obs_clamp;     /* ObsHardMargins = max(0,.) ; 0 in the codegen twin */
+    int obs_type_fixed;/* codegen twin: always NEWCASES */
+} model_ops;
+
+static const model_ops MODEL_TABLE[6] = {
+    /* SIA3          */ {3, 0, 0, 0, 1, 0},
+    /* SIA6          */ {6, 0, 1, 0, 1, 0},
+    /* SIA3_BWD      */ {3, 1, 1, 0, 1, 0},
+    /* SIA6_BWD      */ {6, 1, 1, 0, 1, 0},
+    /* NEWCASE6      */ {6, 0, 1, 1, 1, 0},
+    /* NEWCASE6 twin */ {6, 0, 1, 1, 0, 1},
+};
+
+int orc_model_dim(int model) { return (model >= 0 && model < 6) ? MODEL_TABLE[model].m : -1; }
+
+/* StateHardMargins: SIAlphaModelEKF.m:27-31 ; OptControlled :27-31 ; Backward :48-52 */
+static void state_hard_margins(const model_ops *mo, const orc_params *p, double *s)
+{
+    double slo = mo->lo_is_zero ? 0.0 : p->s_min;
+    double ilo = mo->lo_is_zero ? 0.0 : p->i_min;
+    s[0] = fmin(1.0, fmax(slo, s[0]));
+    s[1] = fmin(1.0, fmax(ilo, s[1]));
+    s[2] = fmin(p->alpha_max, fmax(p->alpha_min, s[2]));
+}
+
+/* bang-bang substitution: SIAlphaModelEKFOptControlled.m:49-58 */
+static void resolve_control(const model_ops *mo, const orc_params *p, const double *s, double *u)
+{
+    if (mo->m != 6) return;
+    for (int kk = 0; kk < p->n_npi; kk++) {
+        if (isnan(u[kk])) {
+            double phi = p->epsilon * p->w_eff[kk] - p->gamma * s[5] * p->a[kk];
+            int lo = mo->phi_ge ? (phi >= 0.0) : (phi > 0.0);
+            u[kk] = lo ? p->u_min[kk] : p->u_max[kk];
+        }
+    }
+}
+
+/* NlinStateUpdate: SIAlphaModelEKF.m:39-48 ; OptControlled :39-74 ; flipped: Backward*.m:60-95 */
+static void nlin_state_update(const model_ops *mo, const orc_params *p, double *u /* in/out */,
+                              const double *s, double *sn)
+{
+    double sg = mo->flipped ? -1.0 : 1.0;
+    double slo = mo->lo_is_zero ? 0.0 : p->s_min;
+    double ilo = mo->lo_is_zero ? 0.0 : p->i_min;
+    resolve_control(mo, p, s, u);
+    /* params.gamma * params.a'*(params.u_max - u): MATLAB evaluates left to
+     * right, i.e. the row vector (gamma*a') times the column (u_max - u) */
+    double dot = 0.0;
+    for (int kk = 0; kk < p->n_npi; kk++) {
+        double term = (p->gamma * p->a[kk]) * (p->u_max[kk] - u[kk]);
+        dot = (kk == 0) ? term : dot + term;
+    }
+    double asi = s[2] * s[0] * s[1]; /* s_k(3) * s_k(1) * s_k(2) */
+    double f3 = -p->gamma * s[2] + p->gamma * p->b + dot;
+    if (!mo->flipped) {
+        sn[0] = fmax(slo, fmin(1.0, s[0] - p->dt * s[2] * s[0] * s[1]));
+        sn[1] = fmax(ilo, fmin(1.0, s[1] + p->dt * (asi - p->beta * s[1])));
+        sn[2] = fmax(p->alpha_min, fmin(p->alpha_max, s[2] + p->dt * f3));
+    } else {
+        sn[0] = fmax(slo, fmin(1.0, s[0] + p->dt * s[2] * s[0] * s[1]));
+        sn[1] = fmax(ilo, fmin(1.0, s[1] - p->dt * (asi - p->beta * s[1])));
+        sn[2] = fmax(p->alpha_min, fmin(p->alpha_max, s[2] - p->dt * f3));
+    }
+    if (mo->m == 6) {
+        double rho = s[3] - s[4] - (1.0 - p->epsilon);
+        double g4 = p->dt * rho * s[2] * s[1];
+        double g5 = p->dt * (rho * s[2] * s[0] + p->beta * s[4]);
+        double g6 = p->dt * (rho * s[0] * s[1] + p->gamma * s[5]);
+        sn[3] = s[3] + sg * g4;
+        sn[4] = s[4] + sg * g5;
+        sn[5] = s[5] + sg * g6;
+    }
+}
+
+/* NlinObsUpdate + ObsHardMargins: SIAlphaModelEKF.m:34-36,51-59 */
+static int predict_obs(const model_ops *mo, const orc_params *p, const double *s, double v_bar, double *xk)
+{
+    int ot = mo->obs_type_fixed ? ORC_OBS_NEWCASES : p->obs_type;
+    double v;
+    if (ot == ORC_OBS_NEWCASES) v = s[0] * s[1] * s[2] + v_bar;
+    else if (ot == ORC_OBS_TOTALCASES) v = 1.0 - s[0] + v_bar;
+    else return ORC_ERR_OBS_TYPE;
+    *xk = mo->obs_clamp ? fmax(0.0, v) : v;
+    return ORC_OK;
+}
+
+/* ObsJacobian: SIAlphaModelEKF.m:79-89 ; OptControlled :138-148 */
+static int obs_jacobian(const model_ops *mo, const orc_params *p, const double *s, double *C)
+{
+    int ot = p->obs_type; /* the codegen twin's ObsJacobian keeps the obs_type test only in Tools/ */
+    if (mo->obs_type_fixed) ot = ORC_OBS_NEWCASES;
+    for (int i = 0; i < mo->m; i++) C[i] = 0.0;
+    if (ot == ORC_OBS_NEWCASES) {
+        C[0] = s[1] * s[2];
+        C[1] = s[0] * s[2];
+        C[2] = s[0] * s[1];
+    } else if (ot == ORC_OBS_TOTALCASES) {
+        C[0] = -1.0;
+    } else return ORC_ERR_OBS_TYPE;
+    return ORC_OK;
+}
+
+/* StateJacobians: SIAlphaModelEKF.m:62-76 ; OptControlled :89-135 ; flipped twins */
+static void state_jacobians(const model_ops *mo, const orc_params *p, const double *u /* original, NaNs kept */,
+                            const double *s, double *A)
+{
+    int m = mo->m;
+    double dt = p->dt;
+    for (int i = 0; i < m * m; i++) A[i] = 0.0;
+    if (!mo->flipped) {
+        A[IX(0, 0, m)] = 1.0 - dt * s[2] * s[1];
+        A[IX(0, 1, m)] = -dt * s[2] * s[0];
+        A[IX(0, 2, m)] = -dt * s[0] * s[1];
+        A[IX(1, 0, m)] = dt * s[1] * s[2];
+        A[IX(1, 1, m)] = 1.0 + dt * (s[0] * s[2] - p->beta);
+        A[IX(1, 2, m)] = dt * s[0] * s[1];
+        A[IX(2, 2, m)] = 1.0 - dt * p->gamma;
+    } else {
+        A[IX(0, 0, m)] = 1.0 + dt * s[2] * s[1];
+        A[IX(0, 1, m)] = dt * s[2] * s[0];
+        A[IX(0, 2, m)] = dt * s[0] * s[1];
+        A[IX(1, 0, m)] = -dt * s[1] * s[2];
+        A[IX(1, 1, m)] = 1.0 - dt * (s[0] * s[2] - p->beta);
+        A[IX(1, 2, m)] = -dt * s[0] * s[1];
+        A[IX(2, 2, m)] = 1.0 + dt * p->gamma;
+    }
+    if (m != 6) return;
+    /* linear-slope term :107-114 */
+    for (int kk = 0; kk < p->n_npi; kk++) {
+        if (isnan(u[kk])) {
+            double phi = p->epsilon * p->w_eff[kk] - p->gamma * s[5] * p->a[kk];
+            if (phi > -1.0 / p->sigma && phi < 1.0 / p->sigma) {
+                double term = p->gamma * dt * (p->sigma / 2.0) * p->a[kk] * (p->u_max[kk] - p->u_min[kk]);
+                if (!mo->flipped) A[IX(2, 5, m)] = A[IX(2, 5, m)] - term;
+                else A[IX(2, 5, m)] = A[IX(2, 5, m)] + term;
+            }
+        }
+    }
+    double rho = s[3] - s[4] - (1.0 - p->epsilon);
+    if (!mo->flipped) {
+        A[IX(3, 1, m)] = dt * s[2] * rho;
+        A[IX(3, 2, m)] = dt * s[1] * rho;
+        A[IX(3, 3, m)] = 1.0 + dt * s[1] * s[2];
+        A[IX(3, 4, m)] = -dt * s[1] * s[2];
+        A[IX(4, 0, m)] = dt * s[2] * rho;
+        A[IX(4, 2, m)] = dt * s[0] * rho;
+        A[IX(4, 3, m)] = dt * s[0] * s[2];
+        A[IX(4, 4, m)] = 1.0 - dt * (s[0] * s[2] - p->beta);
+        A[IX(5, 0, m)] = dt * s[1] * rho;
+        A[IX(5, 1, m)] = dt * s[0] * rho;
+        A[IX(5, 3, m)] = dt * s[0] * s[1];
+        A[IX(5, 4, m)] = -dt * s[0] * s[1];
+        A[IX(5, 5, m)] = 1.0 + dt * p->gamma;
+    } else {
+        A[IX(3, 1, m)] = -dt * s[2] * rho;
+        A[IX(3, 2, m)] = -dt * s[1] * rho;
+        A[IX(3, 3, m)] = 1.0 - dt * s[1] * s[2];
+        A[IX(3, 4, m)] = dt * s[1] * s[2];
+        A[IX(4, 0, m)] = -dt * s[2] * rho;
+        A[IX(4, 2, m)] = -dt * s[0] * rho;
+        A[IX(4, 3, m)] = -dt * s[0] * s[2];
+        A[IX(4, 4, m)] = 1.0 + dt * (s[0] * s[2] - p->beta);
+        A[IX(5, 0, m)] = -dt * s[1] * rho;
+        A[IX(5, 1, m)] = -dt * s[0] * rho;
+        A[IX(5, 3, m)] = -dt * s[0] * s[1];
+        A[IX(5, 4, m)] = dt * s[0] * s[1];
+        A[IX(5, 5, m)] = 1.0 - dt * p->gamma;
+    }
+}
+
+static int has_nonfinite(const double *P, int n)
+{
+    for (int i = 0; i < n; i++)
+        if (isnan(P[i]) || isinf(P[i])) return 1;
+    return 0;
+}
+
+/* ---------- the filter ---------- */
+static int ekf_core(int model, int T, const double *u_in, const double *x, const orc_params *prm,
+                    const double *s_init, const double *Ps_init, const double *s_final,
+                    const double *Ps_final, double v_bar, const double *Q_w, int q_len,
+                    const double *R_v, int r_len, double beta, double gamma, int L, int order,
+                    double *u_opt, double *u_opt_smooth, double *S_MINUS, double *S_PLUS,
+                    double *S_SMOOTH, double *P_MINUS, double *P_PLUS, double *P_SMOOTH,
+                    double *K_GAIN, double *innovations, double *rho, int *pinv_rank)
+{
+    const model_ops *mo = &MODEL_TABLE[model];
+    const int m = mo->m, mm = m * m, nn = prm->n_npi;
+    const int generic = (model <= ORC_MODEL_SIA6_BWD); /* GenericExtendedKalmanFilter vs NewCase... */
+    if (T < 1 || L < 1 || nn < 1 || nn > ORC_MAX_NPI) return ORC_ERR_BAD_ARG;
+    if (q_len != 1 && q_len != T) return ORC_ERR_Q_MISMATCH;
+    if (r_len != 1 && r_len != T) return ORC_ERR_R_MISMATCH;
+    if (!generic && (q_len != 1 || r_len != 1)) return ORC_ERR_BAD_ARG; /* Q = Q_w; R = R_v scalars/matrices */
+    if (order != 1 && order != 2) return ORC_ERR_UNDEFINED_ORDER;
+
+    double *R = (double *)malloc(sizeof(double) * (size_t)T);
+    double *winMean = (double *)calloc((size_t)L, sizeof(double));
+    double *winCov = (double *)calloc((size_t)L, sizeof(double));
+    double *winCovN = (double *)calloc((size_t)L, sizeof(double));
+    double *uo_s = (double *)malloc(sizeof(double) * (size_t)nn * (size_t)T);
+    int rc = ORC_OK;
+    const int fixed_R = (r_len == 1); /* GenericEKF:79-85 */
+    for (int k = 0; k < T; k++) R[k] = fixed_R ? R_v[0] : R_v[k];
+    double Rs = R_v[0]; /* NewCase...:31 scalar running R */
+
+    double sk_minus[MM], Pk_minus[MM * MM], sk_plus[MM], Pk_plus[MM * MM];
+    double C[MM], K[MM], A[MM * MM], T1[MM * MM], T2[MM * MM], IKC[MM * MM], uk[ORC_MAX_NPI];
+    for (int i = 0; i < m; i++) sk_minus[i] = s_init[i];
+    for (int i = 0; i < mm; i++) Pk_minus[i] = Ps_init[i];
+
+    /* Forward Kalman filtering stage: GenericEKF:98-186 / NewCase...:37-113 */
+    for (int k = 0; k < T; k++) {
+        const double *Qk = Q_w + (q_len == 1 ? 0 : (size_t)mm * k);
+        double Rk = generic ? R[k] : Rs;
+        if (S_MINUS) memcpy(S_MINUS + (size_t)m * k, sk_minus, sizeof(double) * m);
+        if (P_MINUS) memcpy(P_MINUS + (size_t)mm * k, Pk_minus, sizeof(double) * mm);
+
+        if ((rc = obs_jacobian(mo, prm, sk_minus, C)) != ORC_OK) goto done;
+        double xk_minus;
+        if ((rc = predict_obs(mo, prm, sk_minus, v_bar, &xk_minus)) != ORC_OK) goto done;
+
+        double innov;
+        if (!isnan(x[k])) {
+            innov = x[k] - xk_minus;
+            /* Kgain = Pk_minus*Ck' / (Ck*Pk_minus*Ck' + gamma*(D*R*D')) */
+            double PCt[MM];
+            for (int i = 0; i < m; i++) {
+                double acc = Pk_minus[IX(i, 0, m)] * C[0];
+                for (int j = 1; j < m; j++) acc = acc + Pk_minus[IX(i, j, m)] * C[j];
+                PCt[i] = acc;
+            }
+            double CP[MM]; /* Ck*Pk_minus (row vector) */
+            for (int j = 0; j < m; j++) {
+                double acc = C[0] * Pk_minus[IX(0, j, m)];
+                for (int i = 1; i < m; i++) acc = acc + C[i] * Pk_minus[IX(i, j, m)];
+                CP[j] = acc;
+            }
+            double CPCt = CP[0] * C[0];
+            for (int j = 1; j < m; j++) CPCt = CPCt + CP[j] * C[j];
+            double den = CPCt + gamma * Rk;
+            for (int i = 0; i < m; i++) K[i] = PCt[i] / den;
+            /* eye(m) - Kgain*Ck */
+            for (int j = 0; j < m; j++)
+                for (int i = 0; i < m; i++) IKC[IX(i, j, m)] = ((i == j) ? 1.0 : 0.0) - K[i] * C[j];
+            if (generic) {
+                /* ((I-KC)*P*(I-KC)' + K*(D*R*D')*K')/gamma   GenericEKF:127 */
+                mat_mul(m, IKC, Pk_minus, T1);
+                mat_mul_bt(m, T1, IKC, T2);
+                for (int j = 0; j < m; j++)
+                    for (int i = 0; i < m; i++)
+                        Pk_plus[IX(i, j, m)] = (T2[IX(i, j, m)] + (K[i] * Rk) * K[j]) / gamma;
+            } else {
+                /* (I-KC)*P/gamma   NewCase...:64 */
+                mat_mul(m, IKC, Pk_minus, T1);
+                for (int i = 0; i < mm; i++) Pk_plus[i] = T1[i] / gamma;
+            }
+            for (int i = 0; i < m; i++) sk_plus[i] = sk_minus[i] + K[i] * innov;
+        } else {
+            innov = 0.0;
+            for (int i = 0; i < m; i++) K[i] = 0.0;
+            for (int i = 0; i < mm; i++) Pk_plus[i] = Pk_minus[i];
+            for (int i = 0; i < m; i++) sk_plus[i] = sk_minus[i];
+        }
+        if (generic) symmetrize(m, Pk_plus); /* :138 */
+        state_hard_margins(mo, prm, sk_plus); /* :141 */
+
+        /* state propagation :155-164 */
+        for (int kk = 0; kk < nn; kk++) uk[kk] = u_in[kk + (size_t)nn * k];
+        nlin_state_update(mo, prm, uk, sk_plus, sk_minus);
+        if (u_opt) memcpy(u_opt + (size_t)nn * k, uk, sizeof(double) * nn);
+        state_jacobians(mo, prm, u_in + (size_t)nn * k, sk_plus, A);
+        mat_mul(m, A, Pk_plus, T1);
+        mat_mul_bt(m, T1, A, T2);
+        for (int i = 0; i < mm; i++) Pk_minus[i] = T2[i] + Qk[i]; /* B = I */
+        if (generic) symmetrize(m, Pk_minus); /* :161 */
+        state_hard_margins(mo, prm, sk_minus); /* :164 */
+
+        if (S_PLUS) memcpy(S_PLUS + (size_t)m * k, sk_plus, sizeof(double) * m);
+        if (P_PLUS) memcpy(P_PLUS + (size_t)mm * k, Pk_plus, sizeof(double) * mm);
+        if (K_GAIN) memcpy(K_GAIN + (size_t)m * k, K, sizeof(double) * m);
+        if (innovations) innovations[k] = innov;
+
+        /* innovation monitor :172-185 (windows are newest-first, summed front to back) */
+        int cnt = (k + 1 < L) ? (k + 1) : L;
+        memmove(winMean + 1, winMean, sizeof(double) * (size_t)(L - 1));
+        winMean[0] = innov;
+        double sum = winMean[0];
+        for (int j = 1; j < L; j++) sum = sum + winMean[j];
+        double mu = sum / (double)cnt;
+        double cc = (innov - mu) * (innov - mu);
+        memmove(winCov + 1, winCov, sizeof(double) * (size_t)(L - 1));
+        winCov[0] = cc;
+        memmove(winCovN + 1, winCovN, sizeof(double) * (size_t)(L - 1));
+        winCovN[0] = generic ? cc / (Rk + DBL_EPS) : cc / Rk;
+        double sumN = winCovN[0];
+        for (int j = 1; j < L; j++) sumN = sumN + winCovN[j];
+        if (rho) rho[k] = sumN / (double)cnt;
+        if (generic) {
+            if (beta != 1.0 && !isnan(x[k]) && fixed_R && k < T - 1) {
+                double sumC = winCov[0];
+                for (int j = 1; j < L; j++) sumC = sumC + winCov[j];
+                R[k + 1] = beta * R[k] + (1.0 - beta) * (sumC / (double)cnt);
+            }
+        } else {
+            if (beta != 1.0 && !isnan(x[k])) {
+                double sumC = winCov[0];
+                for (int j = 1; j < L; j++) sumC = sumC + winCov[j];
+                Rs = beta * Rs + (1.0 - beta) * sumC / (double)cnt;
+            }
+        }
+    }
+
+    /* Backward smoothing stage: GenericEKF:189-230 / NewCase...:115-139.
+     * It needs the stored forward quantities; if the caller did not ask for
+     * them we cannot smooth, so the batch driver always supplies scratch. */
+    if (S_SMOOTH && P_SMOOTH && S_MINUS && S_PLUS && P_MINUS && P_PLUS) {
+        double Ss[MM], Ps[MM * MM], J[MM * MM], Xp[MM * MM], D[MM * MM], dv[MM];
+        for (int i = 0; i < m; i++) Ss[i] = S_PLUS[i + (size_t)m * (T - 1)];
+        for (int i = 0; i < mm; i++) Ps[i] = P_PLUS[i + (size_t)mm * (T - 1)];
+        for (int i = 0; i < m; i++)
+            if (!isnan(s_final[i])) Ss[i] = s_final[i];
+        if (generic) {
+            for (int i = 0; i < mm; i++)
+                if (!isnan(Ps_final[i])) Ps[i] = Ps_final[i];
+        } else {
+            /* P_SMOOTH(row, col, T) = Ps_final(row, col): cross-product sub-assignment :125-127 */
+            int rows[MM] = {0}, cols[MM] = {0}, any = 0;
+            for (int j = 0; j < m; j++)
+                for (int i = 0; i < m; i++)
+                    if (!isnan(Ps_final[IX(i, j, m)])) { rows[i] = 1; cols[j] = 1; any = 1; }
+            if (any)
+                for (int j = 0; j < m; j++)
+                    for (int i = 0; i < m; i++)
+                        if (rows[i] && cols[j]) Ps[IX(i, j, m)] = Ps_final[IX(i, j, m)];
+        }
+        memcpy(S_SMOOTH + (size_t)m * (T - 1), Ss, sizeof(double) * m);
+        memcpy(P_SMOOTH + (size_t)mm * (T - 1), Ps, sizeof(double) * mm);
+        for (int kk = 0; kk < nn; kk++) uo_s[kk + (size_t)nn * (T - 1)] = 0.0; /* column T never written :95,204 */
+        if (pinv_rank) pinv_rank[T - 1] = -1;
+
+        for (int k = T - 2; k >= 0; k--) {
+            const double *Sp = S_PLUS + (size_t)m * k;
+            const double *Pp = P_PLUS + (size_t)mm * k;
+            const double *Sm1 = S_MINUS + (size_t)m * (k + 1);
+            const double *Pm1 = P_MINUS + (size_t)mm * (k + 1);
+            state_jacobians(mo, prm, u_in + (size_t)nn * k, Sp, A);
+            int rank = -1;
+            if (generic) {
+                if (has_nonfinite(Pm1, mm)) {
+                    for (int i = 0; i < mm; i++) J[i] = 0.0; /* :211-213 */
+                } else {
+                    mat_mul_bt(m, Pp, A, T1); /* P_PLUS*A' */
+                    rank = orc_sym_pinv(m, Pm1, Xp);
+                    mat_mul(m, T1, Xp, J);
+                }
+            } else {
+                mat_mul_bt(m, Pp, A, T1);
+                orc_mrdivide(m, T1, Pm1, J); /* :132 */
+            }
+            if (pinv_rank) pinv_rank[k] = rank;
+            for (int i = 0; i < m; i++) dv[i] = Ss[i] - Sm1[i];
+            double Sn[MM];
+            for (int i = 0; i < m; i++) {
+                double acc = J[IX(i, 0, m)] * dv[0];
+                for (int j = 1; j < m; j++) acc = acc + J[IX(i, j, m)] * dv[j];
+                Sn[i] = Sp[i] + acc;
+            }
+            state_hard_margins(mo, prm, Sn);
+            for (int i = 0; i < mm; i++) D[i] = Pm1[i] - Ps[i];
+            mat_mul(m, J, D, T1);
+            mat_mul_bt(m, T1, J, T2);
+            for (int i = 0; i < mm; i++) Ps[i] = Pp[i] - T2[i];
+            if (generic) symmetrize(m, Ps);
+            for (int i = 0; i < m; i++) Ss[i] = Sn[i];
+            memcpy(S_SMOOTH + (size_t)m * k, Ss, sizeof(double) * m);
+            memcpy(P_SMOOTH + (size_t)mm * k, Ps, sizeof(double) * mm);
+            if (generic) {
+                /* rerun the state equation to find the optimal input :229 */
+                double sn_dummy[MM];
+                for (int kk = 0; kk < nn; kk++) uk[kk] = u_in[kk + (size_t)nn * k];
+                nlin_state_update(mo, prm, uk, Ss, sn_dummy);
+                memcpy(uo_s + (size_t)nn * k, uk, sizeof(double) * nn);
+            }
+        }
+        if (generic && u_opt_smooth) memcpy(u_opt_smooth, uo_s, sizeof(double) * (size_t)nn * T);
+    }
+done:
+    free(R); free(winMean); free(winCov); free(winCovN); free(uo_s);
+    return rc;
+}
+
+static void flip_cols(double *a, int rows, int T)
+{
+    if (!a) return;
+    for (int k = 0; k < T / 2; k++)
+        for (int i = 0; i < rows; i++) {
+            double t = a[i + (size_t)rows * k];
+            a[i + (size_t)rows * k] = a[i + (size_t)rows * (T - 1 - k)];
+            a[i + (size_t)rows * (T - 1 - k)] = t;
+        }
+}
+
+int orc_ekf_run(int model, int T, const double *u, const double *x, const orc_params *prm,
+                const double *s_init, const double *Ps_init, const double *s_final,
+                const double *Ps_final, double v_bar, const double *Q_w, int q_len,
+                const double *R_v, int r_len, double beta, double gamma, int L, int order,
+                double *u_opt, double *u_opt_smooth, double *S_MINUS, double *S_PLUS,
+                double *S_SMOOTH, double *P_MINUS, double *P_PLUS, double *P_SMOOTH,
+                double *K_GAIN, double *innovations, double *rho, int *pinv_rank)
+{
+    if (model < 0 || model > 5 || T < 1) return ORC_ERR_BAD_ARG;
+    const model_ops *mo = &MODEL_TABLE[model];
+    const int m = mo->m, mm = m * m, nn = prm->n_npi;
+    /* scratch for forward quantities the smoother needs when the caller passes NULL */
+    double *sm_ = S_MINUS ? NULL : (double *)malloc(sizeof(double) * (size_t)m * T);
+    double *sp_ = S_PLUS ? NULL : (double *)malloc(sizeof(double) * (size_t)m * T);
+    double *pm_ = P_MINUS ? NULL : (double *)malloc(sizeof(double) * (size_t)mm * T);
+    double *pp_ = P_PLUS ? NULL : (double *)malloc(sizeof(double) * (size_t)mm * T);
+    double *ss_ = S_SMOOTH ? NULL : (double *)malloc(sizeof(double) * (size_t)m * T);
+    double *ps_ = P_SMOOTH ? NULL : (double *)malloc(sizeof(double) * (size_t)mm * T);
+    double *SM = S_MINUS ? S_MINUS : sm_, *SP = S_PLUS ? S_PLUS : sp_;
+    double *PM = P_MINUS ? P_MINUS : pm_, *PP = P_PLUS ? P_PLUS : pp_;
+    double *SS = S_SMOOTH ? S_SMOOTH : ss_, *PS = P_SMOOTH ? P_SMOOTH : ps_;
+    int rc;
+    if (!mo->flipped) {
+        rc = ekf_core(model, T, u, x, prm, s_init, Ps_init, s_final, Ps_final, v_bar, Q_w, q_len, R_v,
+                      r_len, beta, gamma, L, order, u_opt, u_opt_smooth, SM, SP, SS, PM, PP, PS,
+                      K_GAIN, innovations, rho, pinv_rank);
+    } else {
+        /* Backward wrappers: SIAlphaModelBackwardEKF.m:19-40 -- flip u and x in
+         * time, swap init/final, run, flip all 11 outputs back.  Q_w and R_v are
+         * passed through UN-flipped, as the reference does (:27). */
+        double *uf = (double *)malloc(sizeof(double) * (size_t)nn * T);
+        double *xf = (double *)malloc(sizeof(double) * (size_t)T);
+        for (int k = 0; k < T; k++) {
+            xf[k] = x[T - 1 - k];
+            for (int kk = 0; kk < nn; kk++) uf[kk + (size_t)nn * k] = u[kk + (size_t)nn * (T - 1 - k)];
+        }
+        rc = ekf_core(model, T, uf, xf, prm, /*s_init_flipped=*/s_final, /*Ps_init_flipped=*/Ps_final,
+                      /*s_final_flipped=*/s_init, /*Ps_final_flipped=*/Ps_init, v_bar, Q_w, q_len, R_v,
+                      r_len, beta, gamma, L, order, u_opt, u_opt_smooth, SM, SP, SS, PM, PP, PS,
+                      K_GAIN, innovations, rho, pinv_rank);
+        if (rc == ORC_OK) {
+            flip_cols(u_opt, nn, T); flip_cols(u_opt_smooth, nn, T);
+            flip_cols(S_MINUS, m, T); flip_cols(S_PLUS, m, T); flip_cols(S_SMOOTH, m, T);
+            flip_cols(P_MINUS, mm, T); flip_cols(P_PLUS, mm, T); flip_cols(P_SMOOTH, mm, T);
+            flip_cols(K_GAIN, m, T); flip_cols(innovations, 1, T); flip_cols(rho, 1, T);
+            if (pinv_rank)
+                for (int k = 0; k < T / 2; k++) { int t = pinv_rank[k]; pinv_rank[k] = pinv_rank[T - 1 - k]; pinv_rank[T - 1 - k] = t; }
+        }
+        free(uf); free(xf);
+    }
+    free(sm_); free(sp_); free(pm_); free(pp_); free(ss_); free(ps_);
+    return rc;
+}
+
+/* ---------- forward simulators ---------- */
+void orc_sialpha_controlled(const double *u, int n_npi, double s0, double i0, double alpha0,
+                            const double *u_max, double alpha_min, double alpha_max, double gamma,
+                            const double *a, double b, double beta, double s_noise_std,
+                            double i_noise_std, double alpha_noise_std, int K, double dt,
+                            const double *z, double *s, double *i, double *alpha)
+{
+    double sp = s0, ip = i0, ap = alpha0; /* SIalpha_Controlled.m:19-21 */
+    for (int t = 0; t < K; t++) {
+        double z1 = z ? z[3 * t + 0] : 0.0, z2 = z ? z[3 * t + 1] : 0.0, z3 = z ? z[3 * t + 2] : 0.0;
+        double dot = 0.0;
+        for (int kk = 0; kk < n_npi; kk++) {
+            double term = (gamma * a[kk]) * (u_max[kk] - u[kk + (size_t)n_npi * t]); /* (gamma*a')*(u_max-u) */
+            dot = (kk == 0) ? term : dot + term;
+        }
+        double sn = fmax(0.0, fmin(1.0, sp - dt * (ap * sp * ip + z1 * s_noise_std)));                 /* :25 */
+        double in = fmax(0.0, fmin(1.0, ip + dt * (ap * sp * ip - beta * ip + z2 * i_noise_std)));     /* :26 */
+        double an = fmax(alpha_min, fmin(alpha_max, ap + dt * (-gamma * ap + gamma * b + dot + z3 * alpha_noise_std))); /* :27 */
+        s[t] = sn; i[t] = in; alpha[t] = an; /* initial sample dropped :30-32 */
+        sp = sn; ip = in; ap = an;
+    }
+}
+
+void orc_si_controlled(const double *alpha, double beta, double s0, double i0, int K, double dt,
+                       double *s, double *i)
+{
+    s[0] = s0; i[0] = i0; /* SI_Controlled.m:15-16 */
+    for (int t = 0; t < K - 1; t++) {
+        s[t + 1] = fmax(0.0, fmin(1.0, s[t] - dt * alpha[t] * s[t] * i[t]));
+        i[t + 1] = fmax(0.0, fmin(1.0, i[t] + dt * (alpha[t] * s[t] * i[t] - beta * i[t])));
+    }
+}
+
+void orc_seirp(const double *alpha_e, const double *alpha_i, const double *kappa, const double *rho,
+               const double *beta, const double *mu, const double *gamma, double s0, double e0,
+               double i0, double r0, double p0, int K, double dt, double *s, double *e, double *i,
+               double *r, double *p)
+{
+    s[0] = s0; e[0] = e0; i[0] = i0; r[0] = r0; p[0] = p0; /* SEIRP.m:20-24 */
+    for (int t = 0; t < K - 1; t++) { /* :26-32 */
+        s[t + 1] = (-alpha_e[t] * s[t] * e[t] - alpha_i[t] * s[t] * i[t] + gamma[t] * r[t]) * dt + s[t];
+        e[t + 1] = (alpha_e[t] * s[t] * e[t] + alpha_i[t] * s[t] * i[t] - kappa[t] * e[t] - rho[t] * e[t]) * dt + e[t];
+        i[t + 1] = (kappa[t] * e[t] - beta[t] * i[t] - mu[t] * i[t]) * dt + i[t];
+        r[t + 1] = (beta[t] * i[t] + rho[t] * e[t] - gamma[t] * r[t]) * dt + r[t];
+        p[t + 1] = (mu[t] * i[t]) * dt + p[t];
+    }
+}
+
+void orc_seirp_saturated(const double *alpha_e, const double *alpha_i, const double *kappa,
+                         const double *rho, const double *gamma, double s0, double e0, double i0,
+                         double r0, double p0, int K, double dt, double beta_0, double beta_s,
+                         double mu_0, double mu_s, double sigma, double i_0, double *s, double *e,
+                         double *i, double *r, double *p)
+{
+    s[0] = s0; e[0] = e0; i[0] = i0; r[0] = r0; p[0] = p0;
+    for (int t = 0; t < K - 1; t++) { /* SEIRPSaturatedResource.m:26-36 */
+        double h = (tanh((i[t] - i_0) / sigma) + 1.0) / 2.0;
+        double beta = (beta_s - beta_0) * h + beta_0;
+        double mu = (mu_s - mu_0) * h + mu_0;
+        s[t + 1] = (-alpha_e[t] * s[t] * e[t] - alpha_i[t] * s[t] * i[t] + gamma[t] * r[t]) * dt + s[t];
+        e[t + 1] = (alpha_e[t] * s[t] * e[t] + alpha_i[t] * s[t] * i[t] - kappa[t] * e[t] - rho[t] * e[t]) * dt + e[t];
+        i[t + 1] = (kappa[t] * e[t] - beta * i[t] - mu * i[t]) * dt + i[t];
+        r[t + 1] = (beta * i[t] + rho[t] * e[t] - gamma[t] * r[t]) * dt + r[t];
+        p[t + 1] = (mu * i[t]) * dt + p[t];
+    }
+}
+
+void orc_npi_cost(const double *newcases, const double *inputs, const double *weights, int n_npi,
+                  int T, double *J0, double *J1)
+{
+    double a0 = 0.0; /* NPICost.m:6  mean(newcases) */
+    for (int t = 0; t < T; t++) a0 = (t == 0) ? newcases[0] : a0 + newcases[t];
+    *J0 = a0 / (double)T;
+    double a1 = 0.0; /* :9-10  mean(weights(:).*inputs(:)) in column-major order */
+    for (size_t e = 0; e < (size_t)n_npi * (size_t)T; e++) {
+        double term = weights[e] * inputs[e];
+        a1 = (e == 0) ? term : a1 + term;
+    }
+    *J1 = a1 / (double)((size_t)n_npi * (size_t)T);
+}
+
+/* ---------- batched SoA driver ---------- */
+int orc_ekf_run_batch(const orc_batch *bt, int n_threads)
+{
+    const int m = orc_model_dim(bt->model);
+    if (m < 0) return ORC_ERR_BAD_ARG;
+    const int mm = m * m, T = bt->T, B = bt->B, Sx = bt->Sx, Su = bt->Su, nn = bt->n_npi;
+    int rc_all = ORC_OK;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel
+    {
+        double *u = (double *)malloc(sizeof(double) * (size_t)nn * T);
+        double *x = (double *)malloc(sizeof(double) * (size_t)T);
+        double *Rv = (double *)malloc(sizeof(double) * (size_t)T);
+        double *uo = (double *)malloc(sizeof(double) * (size_t)nn * T);
+        double *uos = (double *)malloc(sizeof(double) * (size_t)nn * T);
+        double *SM = (double *)malloc(sizeof(double) * (size_t)m * T);
+        double *SP = (double *)malloc(sizeof(double) * (size_t)m * T);
+        double *SS = (double *)malloc(sizeof(double) * (size_t)m * T);
+        double *PM = (double *)malloc(sizeof(double) * (size_t)mm * T);
+        double *PP = (double *)malloc(sizeof(double) * (size_t)mm * T);
+        double *PS = (double *)malloc(sizeof(double) * (size_t)mm * T);
+        double *KG = (double *)malloc(sizeof(double) * (size_t)m * T);
+        double *inn = (double *)malloc(sizeof(double) * (size_t)T);
+        double *rh = (double *)malloc(sizeof(double) * (size_t)T);
+        int *rk = (int *)malloc(sizeof(int) * (size_t)T);
+#pragma omp for schedule(dynamic, 4)
+        for (int c = 0; c < B; c++) {
+            const int sx = bt->x_series_of_chain ? bt->x_series_of_chain[c] : c;
+            const int su = bt->u_series_of_chain ? bt->u_series_of_chain[c] : c;
+            orc_params p;
+            const double *pr = bt->prm;
+#define PRM(f) pr[(size_t)(f) * B + c]
+            p.dt = PRM(EPI_PRM_DT); p.beta = PRM(EPI_PRM_BETA); p.gamma = PRM(EPI_PRM_GAMMA);
+            p.sigma = PRM(EPI_PRM_SIGMA); p.b = PRM(EPI_PRM_B); p.epsilon = PRM(EPI_PRM_EPSILON);
+            p.s_min = PRM(EPI_PRM_S_MIN); p.i_min = PRM(EPI_PRM_I_MIN);
+            p.alpha_min = PRM(EPI_PRM_ALPHA_MIN); p.alpha_max = PRM(EPI_PRM_ALPHA_MAX);
+            for (int kk = 0; kk < ORC_MAX_NPI; kk++) {
+                p.a[kk] = PRM(EPI_PRM_A + kk); p.u_min[kk] = PRM(EPI_PRM_U_MIN + kk);
+                p.u_max[kk] = PRM(EPI_PRM_U_MAX + kk); p.w_eff[kk] = PRM(EPI_PRM_W_EFF + kk);
+            }
+            double v_bar = PRM(EPI_PRM_V_BAR), beta_ekf = PRM(EPI_PRM_BETA_EKF), gamma_ekf = PRM(EPI_PRM_GAMMA_EKF);
+#undef PRM
+            p.n_npi = nn; p.obs_type = bt->obs_type;
+            for (int k = 0; k < T; k++) {
+                x[k] = bt->x[(size_t)k * Sx + sx];
+                for (int kk = 0; kk < nn; kk++) u[kk + (size_t)nn * k] = bt->u[((size_t)k * nn + kk) * Su + su];
+                if (bt->r_mode == 1) Rv[k] = bt->R_series[(size_t)k * Sx + sx];
+            }
+            if (bt->r_mode == 0) Rv[0] = bt->R_scalar[c];
+            double si[MM], sf[MM], Pi[MM * MM], Pf[MM * MM], Q[MM * MM];
+            for (int i = 0; i < m; i++) { si[i] = bt->s_init[(size_t)i * B + c]; sf[i] = bt->s_final[(size_t)i * B + c]; }
+            for (int i = 0; i < mm; i++) {
+                Pi[i] = bt->Ps_init[(size_t)i * B + c]; Pf[i] = bt->Ps_final[(size_t)i * B + c];
+                Q[i] = bt->Q[(size_t)i * B + c];
+            }
+            int rc = orc_ekf_run(bt->model, T, u, x, &p, si, Pi, sf, Pf, v_bar, Q, 1, Rv,
+                                 bt->r_mode == 1 ? T : 1, beta_ekf, gamma_ekf, bt->L, bt->order,
+                                 uo, uos, SM, SP, SS, PM, PP, PS, KG, inn, rh, rk);
+            if (rc != ORC_OK) {
+#pragma omp critical
+                rc_all = rc;
+                continue;
+            }
+            int has_uos = (bt->model <= ORC_MODEL_SIA6_BWD);
+            for (int k = 0; k < T; k++) {
+                for (int kk = 0; kk < nn; kk++) {
+                    if (bt->u_opt) bt->u_opt[((size_t)k * nn + kk) * B + c] = uo[kk + (size_t)nn * k];
+                    if (bt->u_opt_smooth && has_uos) bt->u_opt_smooth[((size_t)k * nn + kk) * B + c] = uos[kk + (size_t)nn * k];
+                }
+                for (int i = 0; i < m; i++) {
+                    if (bt->S_MINUS) bt->S_MINUS[((size_t)k * m + i) * B + c] = SM[i + (size_t)m * k];
+                    if (bt->S_PLUS) bt->S_PLUS[((size_t)k * m + i) * B + c] = SP[i + (size_t)m * k];
+                    if (bt->S_SMOOTH) bt->S_SMOOTH[((size_t)k * m + i) * B + c] = SS[i + (size_t)m * k];
+                    if (bt->K_GAIN) bt->K_GAIN[((size_t)k * m + i) * B + c] = KG[i + (size_t)m * k];
+                }
+                for (int i = 0; i < mm; i++) {
+                    if (bt->P_MINUS) bt->P_MINUS[((size_t)k * mm + i) * B + c] = PM[i + (size_t)mm * k];
+                    if (bt->P_PLUS) bt->P_PLUS[((size_t)k * mm + i) * B + c] = PP[i + (size_t)mm * k];
+                    if (bt->P_SMOOTH) bt->P_SMOOTH[((size_t)k * mm + i) * B + c] = PS[i + (size_t)mm * k];
+                }
+                if (bt->innovations) bt->innovations[(size_t)k * B + c] = inn[k];
+                if (bt->rho) bt->rho[(size_t)k * B + c] = rh[k];
+                if (bt->pinv_rank) bt->pinv_rank[(size_t)k * B + c] = rk[k];
+            }
+        }
+        free(u); free(x); free(Rv); free(uo); free(uos); free(SM); free(SP); free(SS);
+        free(PM); free(PP); free(PS); free(KG); free(inn); free(rh); free(rk);
+    }
+    return rc_all;
+}

@@ -1,0 +1,220 @@
+"""oracle_lib.py -- ctypes loader for oracle/libekf_oracle.so.
+
+TEST INFRASTRUCTURE, NOT PRODUCT CODE: importable only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product package
+(epidemicmodeling_amd) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libekf_oracle.so")
+
+MODEL_IDS = {
+    "SIAlphaModelEKF": 0,
+    "SIAlphaModelEKFOptControlled": 1,
+    "SIAlphaModelBackwardEKF": 2,
+    "SIAlphaModelBackwardEKFOptControlled": 3,
+    "NewCaseEKFEstimatorWithOptimalNPI": 4,
+    "NewCaseEKFEstimatorWithOptimalNPI_codegen": 5,
+}
+MODEL_DIM = {0: 3, 1: 6, 2: 3, 3: 6, 4: 6, 5: 6}
+OBS_IDS = {"NEWCASES": 0, "TOTALCASES": 1}
+ERRORS = {
+    -1: "Undefined order",
+    -2: "Process noise covariance noise mismatch",
+    -3: "Observation noise covariance noise mismatch",
+    -4: "unknown observation type",
+    -5: "bad argument",
+}
+MAX_NPI = 12
+
+
+class OracleError(Exception):
+    pass
+
+
+class _Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in
+                ("dt", "beta", "gamma", "sigma", "b", "epsilon", "s_min", "i_min", "alpha_min", "alpha_max")] + [
+        ("a", C.c_double * MAX_NPI), ("u_min", C.c_double * MAX_NPI),
+        ("u_max", C.c_double * MAX_NPI), ("w_eff", C.c_double * MAX_NPI),
+        ("n_npi", C.c_int), ("obs_type", C.c_int)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("model", "B", "T", "Sx", "Su", "n_npi", "L", "order", "obs_type", "r_mode")] + [
+        ("x_series_of_chain", C.c_void_p), ("u_series_of_chain", C.c_void_p)] + [(n, C.c_void_p) for n in (
+            "x", "u", "R_series", "R_scalar", "prm", "s_init", "Ps_init", "s_final", "Ps_final", "Q",
+            "u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "P_MINUS", "P_PLUS", "P_SMOOTH",
+            "K_GAIN", "innovations", "rho", "pinv_rank")]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(
+            os.path.join(_HERE, "ekf_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "libekf_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_ekf_run.restype = C.c_int
+        _lib.orc_ekf_run_batch.restype = C.c_int
+        _lib.orc_sym_pinv.restype = C.c_int
+    return _lib
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def make_params(p, n_npi, w_eff):
+    """p: any object with the reference's params fields (dict or attribute style)."""
+    g = (lambda k: p[k]) if isinstance(p, dict) else (lambda k: getattr(p, k))
+    cp = _Params()
+    for k in ("dt", "beta", "gamma", "sigma", "b", "epsilon", "s_min", "i_min", "alpha_min", "alpha_max"):
+        setattr(cp, k, float(g(k)))
+    for name, src in (("a", g("a")), ("u_min", g("u_min")), ("u_max", g("u_max")), ("w_eff", w_eff)):
+        v = np.zeros(MAX_NPI)
+        sv = np.asarray(src, dtype=np.float64).reshape(-1)
+        v[:sv.size] = sv
+        getattr(cp, name)[:] = v.tolist()
+    cp.n_npi = int(n_npi)
+    ot = g("obs_type")
+    cp.obs_type = OBS_IDS.get(ot, 99) if isinstance(ot, str) else int(ot)
+    return cp
+
+
+def run(model, u, x, params, w_eff, s_init, Ps_init, s_final, Ps_final, v_bar, Q_w, R_v, beta, gamma,
+        inv_monitor_len, order):
+    """One reference call through the C oracle; MATLAB-shaped in/out (u: n_npi x T ...).
+
+    Returns dict of the 11 outputs (+ 'pinv_rank')."""
+    mid = MODEL_IDS[model] if isinstance(model, str) else int(model)
+    m = MODEL_DIM[mid]
+    u = np.asarray(u, dtype=np.float64)
+    nn, T = u.shape
+    uF = np.asfortranarray(u)
+    x = _f(np.asarray(x).reshape(-1))
+    cp = make_params(params, nn, w_eff)
+    Q = np.asarray(Q_w, dtype=np.float64)
+    if Q.ndim == 2:
+        q_len, Qf = 1, np.asfortranarray(Q)
+    else:
+        q_len, Qf = Q.shape[2], np.asfortranarray(Q)
+    R = np.asarray(R_v, dtype=np.float64).reshape(-1)
+    r_len = R.size
+    out = {
+        "u_opt": np.zeros((nn, T), order="F"), "u_opt_smooth": np.zeros((nn, T), order="F"),
+        "S_MINUS": np.zeros((m, T), order="F"), "S_PLUS": np.zeros((m, T), order="F"),
+        "S_SMOOTH": np.zeros((m, T), order="F"),
+        "P_MINUS": np.zeros((m, m, T), order="F"), "P_PLUS": np.zeros((m, m, T), order="F"),
+        "P_SMOOTH": np.zeros((m, m, T), order="F"),
+        "K_GAIN": np.zeros((m, 1, T), order="F"), "innovations": np.zeros(T), "rho": np.zeros(T),
+    }
+    rank = np.zeros(T, dtype=np.int32)
+    si, Pi = _f(np.asarray(s_init).reshape(-1)), np.asfortranarray(np.asarray(Ps_init, dtype=np.float64))
+    sf, Pf = _f(np.asarray(s_final).reshape(-1)), np.asfortranarray(np.asarray(Ps_final, dtype=np.float64))
+    R = _f(R)
+    rc = lib().orc_ekf_run(
+        C.c_int(mid), C.c_int(T), _dp(uF), _dp(x), C.byref(cp), _dp(si), _dp(Pi), _dp(sf), _dp(Pf),
+        C.c_double(float(v_bar)), _dp(Qf), C.c_int(q_len), _dp(R), C.c_int(r_len),
+        C.c_double(float(beta)), C.c_double(float(gamma)), C.c_int(int(inv_monitor_len)), C.c_int(int(order)),
+        _dp(out["u_opt"]), _dp(out["u_opt_smooth"]), _dp(out["S_MINUS"]), _dp(out["S_PLUS"]),
+        _dp(out["S_SMOOTH"]), _dp(out["P_MINUS"]), _dp(out["P_PLUS"]), _dp(out["P_SMOOTH"]),
+        _dp(out["K_GAIN"]), _dp(out["innovations"]), _dp(out["rho"]),
+        rank.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc != 0:
+        raise OracleError(ERRORS.get(rc, str(rc)))
+    out["pinv_rank"] = rank
+    return out
+
+
+OUT_SHAPES = {  # name -> rows per time step as a function of (m, n_npi)
+    "u_opt": lambda m, n: n, "u_opt_smooth": lambda m, n: n,
+    "S_MINUS": lambda m, n: m, "S_PLUS": lambda m, n: m, "S_SMOOTH": lambda m, n: m,
+    "P_MINUS": lambda m, n: m * m, "P_PLUS": lambda m, n: m * m, "P_SMOOTH": lambda m, n: m * m,
+    "K_GAIN": lambda m, n: m, "innovations": lambda m, n: 1, "rho": lambda m, n: 1,
+}
+
+
+def run_batch(model, T, n_npi, L, order, obs_type, x, u, prm, s_init, Ps_init, s_final, Ps_final, Q,
+              R_series=None, R_scalar=None, x_series=None, u_series=None, n_threads=0, outputs=None):
+    """Batched SoA call (layout of include/epiekf.h).  All arrays are numpy, C-contiguous:
+    x [T,Sx], u [T,n_npi,Su], prm [61,B], s_init [m,B], Ps_init [m*m,B], ...
+    Returns dict name -> array [T,rows,B] ([T,B] for innovations/rho, pinv_rank int32 [T,B])."""
+    mid = MODEL_IDS[model] if isinstance(model, str) else int(model)
+    m = MODEL_DIM[mid]
+    prm = _f(prm)
+    B = prm.shape[1]
+    x = _f(x); u = _f(u)
+    bt = _Batch()
+    bt.model, bt.B, bt.T, bt.Sx, bt.Su, bt.n_npi, bt.L, bt.order = mid, B, T, x.shape[1], u.shape[2], n_npi, L, order
+    bt.obs_type = OBS_IDS[obs_type] if isinstance(obs_type, str) else int(obs_type)
+    bt.r_mode = 1 if R_series is not None else 0
+    keep = [x, u, prm]
+    for name, mp in (("x_series_of_chain", x_series), ("u_series_of_chain", u_series)):
+        if mp is None:
+            setattr(bt, name, None)
+        else:
+            mp = np.ascontiguousarray(mp, dtype=np.int32)
+            keep.append(mp)
+            setattr(bt, name, mp.ctypes.data)
+    bt.x, bt.u, bt.prm = x.ctypes.data, u.ctypes.data, prm.ctypes.data
+    for name, arr in (("R_series", R_series), ("R_scalar", R_scalar), ("s_init", s_init),
+                      ("Ps_init", Ps_init), ("s_final", s_final), ("Ps_final", Ps_final), ("Q", Q)):
+        if arr is None:
+            setattr(bt, name, None)
+        else:
+            a = _f(arr); keep.append(a)
+            setattr(bt, name, a.ctypes.data)
+    names = list(OUT_SHAPES) if outputs is None else list(outputs)
+    out = {}
+    for name in OUT_SHAPES:
+        if name in names:
+            rows = OUT_SHAPES[name](m, n_npi)
+            shape = (T, B) if name in ("innovations", "rho") else (T, rows, B)
+            out[name] = np.zeros(shape)
+            setattr(bt, name, out[name].ctypes.data)
+        else:
+            setattr(bt, name, None)
+    out["pinv_rank"] = np.zeros((T, B), dtype=np.int32)
+    bt.pinv_rank = out["pinv_rank"].ctypes.data
+    rc = lib().orc_ekf_run_batch(C.byref(bt), C.c_int(int(n_threads)))
+    if rc != 0:
+        raise OracleError(ERRORS.get(rc, str(rc)))
+    return out
+
+
+def sym_pinv(A):
+    A = np.asfortranarray(np.asarray(A, dtype=np.float64))
+    m = A.shape[0]
+    X = np.zeros((m, m), order="F")
+    r = lib().orc_sym_pinv(C.c_int(m), _dp(A), _dp(X))
+    return X, r
+
+
+def mrdivide(Bm, A):
+    A = np.asfortranarray(np.asarray(A, dtype=np.float64))
+    Bm = np.asfortranarray(np.asarray(Bm, dtype=np.float64))
+    m = A.shape[0]
+    X = np.zeros((m, m), order="F")
+    lib().orc_mrdivide(C.c_int(m), _dp(Bm), _dp(A), _dp(X))
+    return X
