@@ -1,0 +1,105 @@
+"""ctypes binding of libepiekf.so (the C ABI of include/epiekf.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, importing the
+compute API raises -- the product path never routes through oracle/ or NumPy."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import layout as L
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libepiekf.so")
+
+ABI_SYMBOLS = [
+    "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
+    "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_seirp_sim_device",
+]
+
+
+class EpiError(RuntimeError):
+    """Raised for a negative epi_status; .status holds the code, the message is the reference's
+    own error() text for the four reference errors (include/epiekf.h)."""
+
+    def __init__(self, status: int, msg: str):
+        super().__init__(msg)
+        self.status = status
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "model", "B", "T", "Sx", "Su", "n_npi", "L", "order",
+                                          "obs_type", "r_mode", "q_mode")] + [
+        ("out_mask", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class Inputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x_series", "u_series", "x", "u", "R_series", "R_scalar", "prm",
+                                           "s_init", "Ps_init", "s_final", "Ps_final", "Q")]
+
+
+class Outputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "P_MINUS",
+                                           "P_PLUS", "P_SMOOTH", "K_GAIN", "innovations", "rho", "pinv_rank",
+                                           "status")]
+
+
+class SimDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "B", "K", "Su", "n_npi", "noise", "with_cost", "reserved")]
+
+
+_lib = None
+
+
+def lib():
+    """Load libepiekf.so; raises if absent (build it with __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build the HIP library first "
+                              "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        h = C.CDLL(LIB_PATH)
+        h.epi_abi_version.restype = C.c_int
+        h.epi_status_string.restype = C.c_char_p
+        h.epi_status_string.argtypes = [C.c_int]
+        h.epi_model_dim.restype = C.c_int
+        h.epi_model_dim.argtypes = [C.c_int]
+        h.epi_ekf_validate.restype = C.c_int
+        h.epi_ekf_validate.argtypes = [C.POINTER(BatchDesc), C.c_char_p]
+        h.epi_ekf_workspace_bytes.restype = C.c_size_t
+        h.epi_ekf_workspace_bytes.argtypes = [C.POINTER(BatchDesc)]
+        h.epi_ekf_run_device.restype = C.c_int
+        h.epi_ekf_run_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p,
+                                         C.c_size_t, C.c_void_p, C.c_char_p]
+        h.epi_ekf_run_host.restype = C.c_int
+        h.epi_ekf_run_host.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_int,
+                                       C.c_char_p]
+        h.epi_sialpha_sim_device.restype = C.c_int
+        h.epi_sialpha_sim_device.argtypes = [C.POINTER(SimDesc)] + [C.c_void_p] * 9 + [C.c_void_p, C.c_char_p]
+        h.epi_seirp_sim_device.restype = C.c_int
+        h.epi_seirp_sim_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+        if h.epi_abi_version() != 1:
+            raise ImportError("libepiekf.so ABI version mismatch")
+        _lib = h
+    return _lib
+
+
+def check(rc: int, err_buf) -> None:
+    if rc != 0:
+        msg = err_buf.value.decode(errors="replace") if err_buf is not None and err_buf.value else \
+            lib().epi_status_string(rc).decode()
+        raise EpiError(rc, msg)
+
+
+def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask) -> BatchDesc:
+    d = BatchDesc()
+    d.abi_version = 1
+    d.model = L.MODEL_IDS[model] if isinstance(model, str) else int(model)
+    d.B, d.T, d.Sx, d.Su, d.n_npi, d.L, d.order = int(B), int(T), int(Sx), int(Su), int(n_npi), int(L_), int(order)
+    if isinstance(obs_type, str):
+        d.obs_type = L.OBS_IDS.get(obs_type, 99)   # unknown strings reach the library's own check
+    else:
+        d.obs_type = int(obs_type)
+    d.r_mode, d.q_mode, d.out_mask, d.reserved = int(r_mode), 0, int(out_mask), 0
+    return d

@@ -1,0 +1,477 @@
+// ekf_device.hpp -- device-side building blocks of the EKF/EKS kernels (gfx950).
+//
+// One LANE owns one filter chain: the state vector, the m x m covariances and
+// every temporary live in that lane's VGPRs (fully unrolled, compile-time
+// indices only), so a wavefront advances 64 chains in lock-step with no
+// cross-lane traffic, and every global access is one coalesced 512-byte row
+// of a time-major / chain-minor array.
+//
+// Arithmetic contract: IEEE fp64, one rounding per written operation (the
+// library is built with -ffp-contract=off), evaluated in the order the
+// reference's MATLAB expressions are written (left to right; matrix products
+// as sum_k A(i,k)*B(k,j), k ascending).  Citations: Tools/*.m of the
+// reference, file:line.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/epiekf.h"
+
+namespace epi {
+
+constexpr int kNpi = EPI_MAX_NPI;
+constexpr int kWave = 64;
+constexpr double kEps = 2.220446049250313e-16;  // MATLAB eps
+
+#define EPI_DEV __device__ __forceinline__
+#define IXM(i, j) ((i) + M * (j))
+
+// per-chain model constants: the reference's `params` struct
+struct ChainPrm {
+    double dt, beta, gamma, sigma, b, epsilon, slo, ilo, alpha_min, alpha_max;
+    double a[kNpi], u_min[kNpi], u_max[kNpi], w[kNpi];
+};
+
+// wave-uniform model switches (see MODEL_TABLE in epiekf.hip)
+struct ModelFlags {
+    int lo_is_zero;   // s,i clamps at 0 (OptControlled.m:28-29) instead of s_min/i_min (SIAlphaModelEKF.m:28-29)
+    int phi_ge;       // phi >= 0 (NewCase...m:175) instead of phi > 0 (OptControlled.m:52)
+    int obs_clamp;    // ObsHardMargins = max(0, .) ; identity in MatlabCodeGenerator/ObsHardMargins.m
+    int obs_type;     // resolved observation type
+};
+
+EPI_DEV bool is_nan(double v) { return v != v; }
+EPI_DEV bool is_nonfinite(double v) { return !(fabs(v) <= 1.7976931348623157e308); }
+
+template <int M>
+EPI_DEV void load_prm(ChainPrm &p, const double *__restrict__ prm, int B, int c, int lo_is_zero)
+{
+    auto g = [&](int f) { return prm[(size_t)f * B + c]; };
+    p.dt = g(EPI_PRM_DT); p.beta = g(EPI_PRM_BETA); p.gamma = g(EPI_PRM_GAMMA);
+    p.sigma = g(EPI_PRM_SIGMA); p.b = g(EPI_PRM_B); p.epsilon = g(EPI_PRM_EPSILON);
+    p.slo = lo_is_zero ? 0.0 : g(EPI_PRM_S_MIN);
+    p.ilo = lo_is_zero ? 0.0 : g(EPI_PRM_I_MIN);
+    p.alpha_min = g(EPI_PRM_ALPHA_MIN); p.alpha_max = g(EPI_PRM_ALPHA_MAX);
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) {
+        p.a[k] = g(EPI_PRM_A + k);
+        p.u_max[k] = g(EPI_PRM_U_MAX + k);
+        if (M == 6) {
+            p.u_min[k] = g(EPI_PRM_U_MIN + k);
+            p.w[k] = g(EPI_PRM_W_EFF + k);
+        } else {
+            p.u_min[k] = 0.0; p.w[k] = 0.0;
+        }
+    }
+}
+
+// ---- dense helpers -------------------------------------------------------
+template <int M>
+EPI_DEV void mat_mul(const double (&A)[M * M], const double (&B)[M * M], double (&C)[M * M])
+{
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            double acc = A[IXM(i, 0)] * B[IXM(0, j)];
+#pragma unroll
+            for (int k = 1; k < M; k++) acc = acc + A[IXM(i, k)] * B[IXM(k, j)];
+            C[IXM(i, j)] = acc;
+        }
+}
+template <int M>
+EPI_DEV void mat_mul_bt(const double (&A)[M * M], const double (&B)[M * M], double (&C)[M * M])
+{
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            double acc = A[IXM(i, 0)] * B[IXM(j, 0)];
+#pragma unroll
+            for (int k = 1; k < M; k++) acc = acc + A[IXM(i, k)] * B[IXM(j, k)];
+            C[IXM(i, j)] = acc;
+        }
+}
+template <int M>
+EPI_DEV void symmetrize(double (&P)[M * M])  // (P + P')/2.0   GenericEKF.m:138,161,226
+{
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = j + 1; i < M; i++) {
+            double v = (P[IXM(i, j)] + P[IXM(j, i)]) / 2.0;
+            P[IXM(i, j)] = v;
+            P[IXM(j, i)] = v;
+        }
+#pragma unroll
+    for (int i = 0; i < M; i++) P[IXM(i, i)] = (P[IXM(i, i)] + P[IXM(i, i)]) / 2.0;
+}
+
+// ---- model callbacks -----------------------------------------------------
+// StateHardMargins: SIAlphaModelEKF.m:27-31, OptControlled.m:27-31, Backward*.m:48-52
+template <int M>
+EPI_DEV void state_hard_margins(const ChainPrm &p, double (&s)[M])
+{
+    s[0] = fmin(1.0, fmax(p.slo, s[0]));
+    s[1] = fmin(1.0, fmax(p.ilo, s[1]));
+    s[2] = fmin(p.alpha_max, fmax(p.alpha_min, s[2]));
+}
+
+// bang-bang substitution of NaN controls: OptControlled.m:49-58 (strict >), NewCase...m:172-181 (>=)
+template <int M>
+EPI_DEV void resolve_control(const ChainPrm &p, const ModelFlags &mf, const double (&s)[M], double (&u)[kNpi])
+{
+    if (M == 6) {
+        const double gs6 = p.gamma * s[M == 6 ? 5 : 0];
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) {
+            if (is_nan(u[k])) {
+                double phi = p.epsilon * p.w[k] - gs6 * p.a[k];
+                bool lo = mf.phi_ge ? (phi >= 0.0) : (phi > 0.0);
+                u[k] = lo ? p.u_min[k] : p.u_max[k];
+            }
+        }
+    }
+}
+
+// NlinStateUpdate: SIAlphaModelEKF.m:39-48, OptControlled.m:39-74, Backward*.m:60-95.
+// `u` comes in with NaNs and leaves as the control actually applied (u_opt).
+template <int M, int FLIP>
+EPI_DEV void nlin_state_update(const ChainPrm &p, const ModelFlags &mf, double (&u)[kNpi],
+                               const double (&s)[M], double (&sn)[M])
+{
+    resolve_control<M>(p, mf, s, u);
+    // params.gamma * params.a' * (params.u_max - u): row vector (gamma*a') times column
+    double dot = (p.gamma * p.a[0]) * (p.u_max[0] - u[0]);
+#pragma unroll
+    for (int k = 1; k < kNpi; k++) dot = dot + (p.gamma * p.a[k]) * (p.u_max[k] - u[k]);
+    const double asi = s[2] * s[0] * s[1];
+    const double f3 = -p.gamma * s[2] + p.gamma * p.b + dot;
+    if (!FLIP) {
+        sn[0] = fmax(p.slo, fmin(1.0, s[0] - p.dt * s[2] * s[0] * s[1]));
+        sn[1] = fmax(p.ilo, fmin(1.0, s[1] + p.dt * (asi - p.beta * s[1])));
+        sn[2] = fmax(p.alpha_min, fmin(p.alpha_max, s[2] + p.dt * f3));
+    } else {
+        sn[0] = fmax(p.slo, fmin(1.0, s[0] + p.dt * s[2] * s[0] * s[1]));
+        sn[1] = fmax(p.ilo, fmin(1.0, s[1] - p.dt * (asi - p.beta * s[1])));
+        sn[2] = fmax(p.alpha_min, fmin(p.alpha_max, s[2] - p.dt * f3));
+    }
+    if (M == 6) {
+        constexpr int i3 = (M == 6) ? 3 : 0, i4 = (M == 6) ? 4 : 0, i5 = (M == 6) ? 5 : 0;
+        const double rho = s[i3] - s[i4] - (1.0 - p.epsilon);
+        const double g4 = p.dt * rho * s[2] * s[1];
+        const double g5 = p.dt * (rho * s[2] * s[0] + p.beta * s[i4]);
+        const double g6 = p.dt * (rho * s[0] * s[1] + p.gamma * s[i5]);
+        if (!FLIP) { sn[i3] = s[i3] + g4; sn[i4] = s[i4] + g5; sn[i5] = s[i5] + g6; }
+        else       { sn[i3] = s[i3] - g4; sn[i4] = s[i4] - g5; sn[i5] = s[i5] - g6; }
+    }
+}
+
+// NlinObsUpdate + ObsHardMargins: SIAlphaModelEKF.m:34-36,51-59
+template <int M>
+EPI_DEV double predict_obs(const ModelFlags &mf, const double (&s)[M], double v_bar)
+{
+    double v = (mf.obs_type == EPI_OBS_NEWCASES) ? (s[0] * s[1] * s[2] + v_bar) : (1.0 - s[0] + v_bar);
+    return mf.obs_clamp ? fmax(0.0, v) : v;
+}
+
+// ObsJacobian: SIAlphaModelEKF.m:79-89, OptControlled.m:138-148
+template <int M>
+EPI_DEV void obs_jacobian(const ModelFlags &mf, const double (&s)[M], double (&C)[M])
+{
+#pragma unroll
+    for (int i = 0; i < M; i++) C[i] = 0.0;
+    if (mf.obs_type == EPI_OBS_NEWCASES) {
+        C[0] = s[1] * s[2];
+        C[1] = s[0] * s[2];
+        C[2] = s[0] * s[1];
+    } else {
+        C[0] = -1.0;
+    }
+}
+
+// StateJacobians: SIAlphaModelEKF.m:62-76, OptControlled.m:89-135, Backward*.m:83-97 / :109-156.
+// `u` is the ORIGINAL control column (NaNs kept), GenericEKF.m:157,206.
+template <int M, int FLIP>
+EPI_DEV void state_jacobians(const ChainPrm &p, const double (&u)[kNpi], const double (&s)[M], double (&A)[M * M])
+{
+    const double dt = p.dt;
+#pragma unroll
+    for (int i = 0; i < M * M; i++) A[i] = 0.0;
+    if (!FLIP) {
+        A[IXM(0, 0)] = 1.0 - dt * s[2] * s[1];
+        A[IXM(0, 1)] = -dt * s[2] * s[0];
+        A[IXM(0, 2)] = -dt * s[0] * s[1];
+        A[IXM(1, 0)] = dt * s[1] * s[2];
+        A[IXM(1, 1)] = 1.0 + dt * (s[0] * s[2] - p.beta);
+        A[IXM(1, 2)] = dt * s[0] * s[1];
+        A[IXM(2, 2)] = 1.0 - dt * p.gamma;
+    } else {
+        A[IXM(0, 0)] = 1.0 + dt * s[2] * s[1];
+        A[IXM(0, 1)] = dt * s[2] * s[0];
+        A[IXM(0, 2)] = dt * s[0] * s[1];
+        A[IXM(1, 0)] = -dt * s[1] * s[2];
+        A[IXM(1, 1)] = 1.0 - dt * (s[0] * s[2] - p.beta);
+        A[IXM(1, 2)] = -dt * s[0] * s[1];
+        A[IXM(2, 2)] = 1.0 + dt * p.gamma;
+    }
+    if (M == 6) {
+        constexpr int i3 = (M == 6) ? 3 : 0, i4 = (M == 6) ? 4 : 0, i5 = (M == 6) ? 5 : 0;
+        // linear-slope term of the bang-bang control, OptControlled.m:107-114
+        const double gs6 = p.gamma * s[i5];
+        const double inv_sigma = 1.0 / p.sigma;
+        double a36 = 0.0;
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) {
+            if (is_nan(u[k])) {
+                double phi = p.epsilon * p.w[k] - gs6 * p.a[k];
+                if (phi > -inv_sigma && phi < inv_sigma) {
+                    double term = p.gamma * dt * (p.sigma / 2.0) * p.a[k] * (p.u_max[k] - p.u_min[k]);
+                    a36 = FLIP ? (a36 + term) : (a36 - term);
+                }
+            }
+        }
+        A[IXM(2, i5)] = a36;
+        const double rho = s[i3] - s[i4] - (1.0 - p.epsilon);
+        if (!FLIP) {
+            A[IXM(i3, 1)] = dt * s[2] * rho;
+            A[IXM(i3, 2)] = dt * s[1] * rho;
+            A[IXM(i3, i3)] = 1.0 + dt * s[1] * s[2];
+            A[IXM(i3, i4)] = -dt * s[1] * s[2];
+            A[IXM(i4, 0)] = dt * s[2] * rho;
+            A[IXM(i4, 2)] = dt * s[0] * rho;
+            A[IXM(i4, i3)] = dt * s[0] * s[2];
+            A[IXM(i4, i4)] = 1.0 - dt * (s[0] * s[2] - p.beta);
+            A[IXM(i5, 0)] = dt * s[1] * rho;
+            A[IXM(i5, 1)] = dt * s[0] * rho;
+            A[IXM(i5, i3)] = dt * s[0] * s[1];
+            A[IXM(i5, i4)] = -dt * s[0] * s[1];
+            A[IXM(i5, i5)] = 1.0 + dt * p.gamma;
+        } else {
+            A[IXM(i3, 1)] = -dt * s[2] * rho;
+            A[IXM(i3, 2)] = -dt * s[1] * rho;
+            A[IXM(i3, i3)] = 1.0 - dt * s[1] * s[2];
+            A[IXM(i3, i4)] = dt * s[1] * s[2];
+            A[IXM(i4, 0)] = -dt * s[2] * rho;
+            A[IXM(i4, 2)] = -dt * s[0] * rho;
+            A[IXM(i4, i3)] = -dt * s[0] * s[2];
+            A[IXM(i4, i4)] = 1.0 + dt * (s[0] * s[2] - p.beta);
+            A[IXM(i5, 0)] = -dt * s[1] * rho;
+            A[IXM(i5, 1)] = -dt * s[0] * rho;
+            A[IXM(i5, i3)] = -dt * s[0] * s[1];
+            A[IXM(i5, i4)] = dt * s[0] * s[1];
+            A[IXM(i5, i5)] = 1.0 - dt * p.gamma;
+        }
+    }
+}
+
+// ---- MATLAB pinv of a symmetric matrix ------------------------------------
+// pinv.m: svd, tol = max(size(A))*eps(norm(s,inf)), keep s > tol.  Symmetric
+// argument => singular triplets from the eigen-decomposition; cyclic Jacobi
+// (Rutishauser's formulation with b/z accumulators) on A scaled by a power of 2.
+EPI_DEV double eps_of(double x)
+{
+    if (x == 0.0) return 4.9406564584124654e-324;
+    int e = ilogb(x);
+    if (e < -1022) return 4.9406564584124654e-324;
+    return ldexp(1.0, e - 52);
+}
+
+constexpr int kJacobiMaxSweeps = 50;
+
+template <int M>
+EPI_DEV void jacobi_rot(double &x, double &y, double s, double tau)
+{
+    double g = x, h = y;
+    x = g - s * (h + g * tau);
+    y = h + s * (g - h * tau);
+}
+
+// a: symmetric, only the upper triangle (i <= j) is read/updated.  Returns true if the sweep cap was hit.
+template <int M>
+EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
+{
+    double b[M], z[M];
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) v[IXM(i, j)] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < M; i++) { b[i] = d[i] = a[IXM(i, i)]; z[i] = 0.0; }
+    bool capped = true;
+    for (int sweep = 1; sweep <= kJacobiMaxSweeps; sweep++) {
+        double sm = 0.0;
+#pragma unroll
+        for (int p = 0; p < M - 1; p++)
+#pragma unroll
+            for (int q = p + 1; q < M; q++) sm = sm + fabs(a[IXM(p, q)]);
+        if (sm == 0.0) { capped = false; break; }
+        const double tresh = (sweep < 4) ? 0.2 * sm / (double)(M * M) : 0.0;
+#pragma unroll
+        for (int p = 0; p < M - 1; p++) {
+#pragma unroll
+            for (int q = p + 1; q < M; q++) {
+                const double apq = a[IXM(p, q)];
+                const double g = 100.0 * fabs(apq);
+                if (sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q])) {
+                    a[IXM(p, q)] = 0.0;
+                } else if (fabs(apq) > tresh) {
+                    double h = d[q] - d[p];
+                    double t;
+                    if ((fabs(h) + g) == fabs(h)) {
+                        t = apq / h;
+                    } else {
+                        double theta = 0.5 * h / apq;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    const double c = 1.0 / sqrt(1.0 + t * t);
+                    const double s = t * c;
+                    const double tau = s / (1.0 + c);
+                    h = t * apq;
+                    z[p] = z[p] - h;
+                    z[q] = z[q] + h;
+                    d[p] = d[p] - h;
+                    d[q] = d[q] + h;
+                    a[IXM(p, q)] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < p; j++) jacobi_rot<M>(a[IXM(j, p)], a[IXM(j, q)], s, tau);
+#pragma unroll
+                    for (int j = p + 1; j < q; j++) jacobi_rot<M>(a[IXM(p, j)], a[IXM(j, q)], s, tau);
+#pragma unroll
+                    for (int j = q + 1; j < M; j++) jacobi_rot<M>(a[IXM(p, j)], a[IXM(q, j)], s, tau);
+#pragma unroll
+                    for (int j = 0; j < M; j++) jacobi_rot<M>(v[IXM(j, p)], v[IXM(j, q)], s, tau);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) { b[i] = b[i] + z[i]; d[i] = b[i]; z[i] = 0.0; }
+    }
+    return capped;
+}
+
+// X = pinv(A) for symmetric A; returns the rank kept.  *capped: Jacobi hit the sweep cap.
+template <int M>
+EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped)
+{
+    double a[M * M], d[M], v[M * M];
+    double amax = 0.0;
+#pragma unroll
+    for (int i = 0; i < M * M; i++) amax = fmax(amax, fabs(A[i]));
+#pragma unroll
+    for (int i = 0; i < M * M; i++) X[i] = 0.0;
+    *capped = false;
+    if (amax == 0.0) return 0;
+    const int e = ilogb(amax);
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) a[IXM(i, j)] = ldexp(A[IXM(i <= j ? i : j, i <= j ? j : i)], -e);
+    *capped = jacobi_eig<M>(a, d, v);
+    double smax = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; i++) smax = fmax(smax, fabs(d[i]));
+    const double tol = (double)M * eps_of(smax);
+    int rank = 0;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const double sv = fabs(d[i]);
+        if (sv > tol) {
+            rank++;
+            const double inv = 1.0 / sv;
+            const double sg = (d[i] < 0.0) ? -1.0 : 1.0;
+#pragma unroll
+            for (int c = 0; c < M; c++)
+#pragma unroll
+                for (int r = 0; r < M; r++)
+                    X[IXM(r, c)] = X[IXM(r, c)] + (v[IXM(r, i)] * inv) * (sg * v[IXM(c, i)]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < M * M; i++) X[i] = ldexp(X[i], -e);
+    return rank;
+}
+
+// ---- MATLAB mrdivide, square right operand: X = Bm / A = (A' \ Bm')' -------
+// LAPACK dgetf2 + dgetrs operation order (first-max partial pivoting, reciprocal
+// scaling of the sub-column, column-oriented triangular solves).  All indices are
+// compile-time; the pivot row is chosen with predicated swaps.
+template <int M>
+EPI_DEV void mrdivide(const double (&Bm)[M * M], const double (&A)[M * M], double (&X)[M * M])
+{
+    double Mt[M * M], Y[M * M];
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) { Mt[IXM(i, j)] = A[IXM(j, i)]; Y[IXM(i, j)] = Bm[IXM(j, i)]; }
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        // idamax over rows j..M-1 of column j: first index of the maximum |.|
+        int piv = j;
+        double best = fabs(Mt[IXM(j, j)]);
+#pragma unroll
+        for (int i = j + 1; i < M; i++) {
+            double vv = fabs(Mt[IXM(i, j)]);
+            if (vv > best) { best = vv; piv = i; }
+        }
+        // pivot value (selected without dynamic indexing)
+        double pval = Mt[IXM(j, j)];
+#pragma unroll
+        for (int i = j + 1; i < M; i++) pval = (piv == i) ? Mt[IXM(i, j)] : pval;
+        const bool nz = (pval != 0.0);
+        // swap rows j <-> piv of the matrix (all columns) and of the right-hand sides (dlaswp)
+#pragma unroll
+        for (int i = j + 1; i < M; i++) {
+            const bool sw = (piv == i);
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+                // dgetf2 swaps only when the pivot is non-zero; dgetrs applies ipiv regardless
+                double mj = Mt[IXM(j, c)], mi = Mt[IXM(i, c)];
+                Mt[IXM(j, c)] = (sw && nz) ? mi : mj;
+                Mt[IXM(i, c)] = (sw && nz) ? mj : mi;
+                double yj = Y[IXM(j, c)], yi = Y[IXM(i, c)];
+                Y[IXM(j, c)] = sw ? yi : yj;
+                Y[IXM(i, c)] = sw ? yj : yi;
+            }
+        }
+        if (nz) {
+            if (fabs(Mt[IXM(j, j)]) >= 2.2250738585072014e-308) {
+                const double r = 1.0 / Mt[IXM(j, j)];
+#pragma unroll
+                for (int i = j + 1; i < M; i++) Mt[IXM(i, j)] = Mt[IXM(i, j)] * r;
+            } else {
+#pragma unroll
+                for (int i = j + 1; i < M; i++) Mt[IXM(i, j)] = Mt[IXM(i, j)] / Mt[IXM(j, j)];
+            }
+        }
+#pragma unroll
+        for (int c = j + 1; c < M; c++)
+#pragma unroll
+            for (int i = j + 1; i < M; i++) Mt[IXM(i, c)] = Mt[IXM(i, c)] - Mt[IXM(i, j)] * Mt[IXM(j, c)];
+    }
+#pragma unroll
+    for (int c = 0; c < M; c++) {
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            if (Y[IXM(k, c)] != 0.0) {
+#pragma unroll
+                for (int i = k + 1; i < M; i++) Y[IXM(i, c)] = Y[IXM(i, c)] - Y[IXM(k, c)] * Mt[IXM(i, k)];
+            }
+        }
+#pragma unroll
+        for (int k = M - 1; k >= 0; k--) {
+            if (Y[IXM(k, c)] != 0.0) {
+                Y[IXM(k, c)] = Y[IXM(k, c)] / Mt[IXM(k, k)];
+#pragma unroll
+                for (int i = 0; i < k; i++) Y[IXM(i, c)] = Y[IXM(i, c)] - Y[IXM(k, c)] * Mt[IXM(i, k)];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) X[IXM(i, j)] = Y[IXM(j, i)];
+}
+
+}  // namespace epi

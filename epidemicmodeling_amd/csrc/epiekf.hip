@@ -1,0 +1,762 @@
+// epiekf.hip -- kernels and C ABI of libepiekf.so (see include/epiekf.h).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared epiekf.hip -o libepiekf.so
+//
+// Kernels
+//   ekf_fwd<M,FLIP,GENERIC>  forward EKF loop, Tools/GenericExtendedKalmanFilter.m:98-186
+//                            (GENERIC=0: Tools/NewCaseEKFEstimatorWithOptimalNPI.m:37-113)
+//   eks_bwd<M,FLIP,GENERIC>  backward smoother loop, GenericEKF.m:189-230 (NewCase...m:115-139)
+// Both keep one chain per lane (ekf_device.hpp); 64-thread workgroups so that the
+// B/64 waves spread over the 1024 SIMDs of the chip as evenly as the batch allows.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "ekf_device.hpp"
+
+namespace epi {
+
+struct ModelInfo { int m, flipped, lo_is_zero, phi_ge, obs_clamp, obs_fixed, generic; };
+static const ModelInfo MODEL_TABLE[6] = {
+    /* SIA3             */ {3, 0, 0, 0, 1, 0, 1},
+    /* SIA6             */ {6, 0, 1, 0, 1, 0, 1},
+    /* SIA3_BWD         */ {3, 1, 1, 0, 1, 0, 1},
+    /* SIA6_BWD         */ {6, 1, 1, 0, 1, 0, 1},
+    /* NEWCASE6         */ {6, 0, 1, 1, 1, 0, 0},
+    /* NEWCASE6_CODEGEN */ {6, 0, 1, 1, 0, 1, 0},
+};
+
+struct KArgs {
+    int B, T, Sx, Su, n_npi, L, r_mode;
+    ModelFlags mf;
+    const int32_t *x_series, *u_series;
+    const double *x, *u, *R_series, *R_scalar, *prm;
+    const double *s_init, *Ps_init, *s_final, *Ps_final, *Q;   // already swapped for flipped models
+    // forward quantities (outputs or workspace; never NULL)
+    double *S_MINUS, *S_PLUS, *P_MINUS, *P_PLUS;
+    // optional outputs (NULL = not stored)
+    double *u_opt, *u_opt_smooth, *S_SMOOTH, *P_SMOOTH, *K_GAIN, *innovations, *rho;
+    int32_t *pinv_rank, *status;
+};
+
+// position in the caller's time axis of filter step k (flipped wrappers run the
+// generic filter on time-reversed u/x and reverse every output: Backward*.m:19-40)
+template <int FLIP> EPI_DEV int tpos(int k, int T) { return FLIP ? (T - 1 - k) : k; }
+
+template <int M>
+EPI_DEV void store_vec(double *__restrict__ dst, int t, int B, int c, const double (&v)[M])
+{
+    if (!dst) return;
+#pragma unroll
+    for (int i = 0; i < M; i++) dst[((size_t)t * M + i) * B + c] = v[i];
+}
+template <int M>
+EPI_DEV void store_mat(double *__restrict__ dst, int t, int B, int c, const double (&P)[M * M])
+{
+    if (!dst) return;
+#pragma unroll
+    for (int e = 0; e < M * M; e++) dst[((size_t)t * (M * M) + e) * B + c] = P[e];
+}
+template <int M>
+EPI_DEV void load_vec(const double *__restrict__ src, int t, int B, int c, double (&v)[M])
+{
+#pragma unroll
+    for (int i = 0; i < M; i++) v[i] = src[((size_t)t * M + i) * B + c];
+}
+template <int M>
+EPI_DEV void load_mat(const double *__restrict__ src, int t, int B, int c, double (&P)[M * M])
+{
+#pragma unroll
+    for (int e = 0; e < M * M; e++) P[e] = src[((size_t)t * (M * M) + e) * B + c];
+}
+EPI_DEV void load_u(const KArgs &a, int t, int su, double (&u)[kNpi])
+{
+#pragma unroll
+    for (int k = 0; k < kNpi; k++)
+        u[k] = (k < a.n_npi) ? a.u[((size_t)t * a.n_npi + k) * a.Su + su] : 0.0;
+}
+EPI_DEV void store_u(double *__restrict__ dst, const KArgs &a, int t, int c, const double (&u)[kNpi])
+{
+    if (!dst) return;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++)
+        if (k < a.n_npi) dst[((size_t)t * a.n_npi + k) * a.B + c] = u[k];
+}
+
+// ---------------------------------------------------------------------------
+// forward pass
+// ---------------------------------------------------------------------------
+template <int M, int FLIP, int GENERIC>
+__global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
+{
+    extern __shared__ double lds[];   // three sliding windows [3][L][64], one column per lane
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * kWave + lane;
+    if (c >= a.B) return;
+    const int B = a.B, T = a.T, L = a.L;
+    const int sx = a.x_series ? a.x_series[c] : c;
+    const int su = a.u_series ? a.u_series[c] : c;
+
+    ChainPrm p;
+    load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero);
+    const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
+    const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
+    const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
+
+    double sk_minus[M], Pk_minus[M * M], Q[M * M];
+#pragma unroll
+    for (int i = 0; i < M; i++) sk_minus[i] = a.s_init[(size_t)i * B + c];
+#pragma unroll
+    for (int e = 0; e < M * M; e++) {
+        Pk_minus[e] = a.Ps_init[(size_t)e * B + c];
+        Q[e] = a.Q[(size_t)e * B + c];
+    }
+    double *winMean = lds + lane, *winCov = lds + (size_t)L * kWave + lane, *winCovN = lds + (size_t)2 * L * kWave + lane;
+    for (int j = 0; j < L; j++) { winMean[j * kWave] = 0.0; winCov[j * kWave] = 0.0; winCovN[j * kWave] = 0.0; }
+    int head = 0;
+
+    const bool fixed_R = (a.r_mode == 0);            // GenericEKF.m:79-85
+    const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
+    double R_next = R_v;                              // R(:,:,k+1) as left by step k (GENERIC) / running R (NewCase)
+
+    for (int k = 0; k < T; k++) {
+        const int t = tpos<FLIP>(k, T);
+        // R_v is NOT time-flipped by the backward wrappers (Backward*.m:27 passes it through)
+        const double Rk = fixed_R ? R_next : a.R_series[(size_t)k * a.Sx + sx];
+        const double xk = a.x[(size_t)t * a.Sx + sx];
+        double u_in[kNpi];
+        load_u(a, t, su, u_in);
+
+        store_vec<M>(a.S_MINUS, t, B, c, sk_minus);       // :100-101
+        store_mat<M>(a.P_MINUS, t, B, c, Pk_minus);
+
+        double C[M];
+        obs_jacobian<M>(a.mf, sk_minus, C);               // :115
+        const double xk_minus = predict_obs<M>(a.mf, sk_minus, v_bar);  // :116-119
+
+        double innov, K[M], sk_plus[M], Pk_plus[M * M];
+        const bool valid = !is_nan(xk);                   // :122
+        if (valid) {
+            innov = xk - xk_minus;
+            double PCt[M], CP[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double acc = Pk_minus[IXM(i, 0)] * C[0];
+#pragma unroll
+                for (int j = 1; j < M; j++) acc = acc + Pk_minus[IXM(i, j)] * C[j];
+                PCt[i] = acc;
+            }
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                double acc = C[0] * Pk_minus[IXM(0, j)];
+#pragma unroll
+                for (int i = 1; i < M; i++) acc = acc + C[i] * Pk_minus[IXM(i, j)];
+                CP[j] = acc;
+            }
+            double CPCt = CP[0] * C[0];
+#pragma unroll
+            for (int j = 1; j < M; j++) CPCt = CPCt + CP[j] * C[j];
+            const double den = CPCt + gamma * Rk;          // :124 (D = 1, Hessian terms 0)
+#pragma unroll
+            for (int i = 0; i < M; i++) K[i] = PCt[i] / den;
+            double IKC[M * M], T1[M * M];
+#pragma unroll
+            for (int j = 0; j < M; j++)
+#pragma unroll
+                for (int i = 0; i < M; i++) IKC[IXM(i, j)] = ((i == j) ? 1.0 : 0.0) - K[i] * C[j];
+            mat_mul<M>(IKC, Pk_minus, T1);
+            if (GENERIC) {
+                double T2[M * M];
+                mat_mul_bt<M>(T1, IKC, T2);                // Joseph form :127
+#pragma unroll
+                for (int j = 0; j < M; j++)
+#pragma unroll
+                    for (int i = 0; i < M; i++)
+                        Pk_plus[IXM(i, j)] = (T2[IXM(i, j)] + (K[i] * Rk) * K[j]) / gamma;
+            } else {
+#pragma unroll
+                for (int e = 0; e < M * M; e++) Pk_plus[e] = T1[e] / gamma;   // NewCase...m:64
+            }
+#pragma unroll
+            for (int i = 0; i < M; i++) sk_plus[i] = sk_minus[i] + K[i] * innov;   // :129
+        } else {                                           // :130-135
+            innov = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) { K[i] = 0.0; sk_plus[i] = sk_minus[i]; }
+#pragma unroll
+            for (int e = 0; e < M * M; e++) Pk_plus[e] = Pk_minus[e];
+        }
+        if (GENERIC) symmetrize<M>(Pk_plus);               // :138
+        state_hard_margins<M>(p, sk_plus);                 // :141
+
+        // s(k+1|k), P(k+1|k)  :155-164
+        double u_app[kNpi];
+#pragma unroll
+        for (int q = 0; q < kNpi; q++) u_app[q] = u_in[q];
+        nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
+        store_u(a.u_opt, a, t, c, u_app);
+        {
+            double A[M * M], T1[M * M], T2[M * M];
+            state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
+            mat_mul<M>(A, Pk_plus, T1);
+            mat_mul_bt<M>(T1, A, T2);
+#pragma unroll
+            for (int e = 0; e < M * M; e++) Pk_minus[e] = T2[e] + Q[e];   // B = I
+        }
+        if (GENERIC) symmetrize<M>(Pk_minus);              // :161
+        state_hard_margins<M>(p, sk_minus);                // :164
+
+        store_vec<M>(a.S_PLUS, t, B, c, sk_plus);          // :167-169
+        store_mat<M>(a.P_PLUS, t, B, c, Pk_plus);
+        store_vec<M>(a.K_GAIN, t, B, c, K);
+        if (a.innovations) a.innovations[(size_t)t * B + c] = innov;
+
+        // innovation monitor :172-185 -- windows are newest-first and summed front to back
+        const int cnt = (k + 1 < L) ? (k + 1) : L;
+        head = (head == 0) ? (L - 1) : (head - 1);
+        winMean[head * kWave] = innov;
+        double sum = innov;
+        {
+            int idx = head;
+            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sum = sum + winMean[idx * kWave]; }
+        }
+        const double mu = sum / (double)cnt;
+        const double cc = (innov - mu) * (innov - mu);
+        const double ccn = GENERIC ? cc / (Rk + kEps) : cc / Rk;
+        winCov[head * kWave] = cc;
+        winCovN[head * kWave] = ccn;
+        double sumN = ccn;
+        {
+            int idx = head;
+            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumN = sumN + winCovN[idx * kWave]; }
+        }
+        if (a.rho) a.rho[(size_t)t * B + c] = sumN / (double)cnt;
+        if (fixed_R) {
+            const bool adapt = GENERIC ? (beta != 1.0 && valid && k < T - 1) : (beta != 1.0 && valid);
+            if (adapt) {
+                double sumC = cc;
+                int idx = head;
+                for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumC = sumC + winCov[idx * kWave]; }
+                if (GENERIC) R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);   // :184
+                else R_next = beta * Rk + (1.0 - beta) * sumC / (double)cnt;             // NewCase...m:111
+            } else if (GENERIC) {
+                R_next = R_v;   // R(k+1) keeps its initial value when step k does not write it
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward pass (fixed-interval smoother)
+// ---------------------------------------------------------------------------
+template <int M, int FLIP, int GENERIC>
+__global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
+{
+    const int c = blockIdx.x * kWave + threadIdx.x;
+    if (c >= a.B) return;
+    const int B = a.B, T = a.T;
+    const int su = a.u_series ? a.u_series[c] : c;
+    ChainPrm p;
+    load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero);
+
+    // terminal conditions :189-202
+    double Ss[M], Ps[M * M];
+    const int tT = tpos<FLIP>(T - 1, T);
+    load_vec<M>(a.S_PLUS, tT, B, c, Ss);
+    load_mat<M>(a.P_PLUS, tT, B, c, Ps);
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        double f = a.s_final[(size_t)i * B + c];
+        if (!is_nan(f)) Ss[i] = f;
+    }
+    {
+        double Pf[M * M];
+#pragma unroll
+        for (int e = 0; e < M * M; e++) Pf[e] = a.Ps_final[(size_t)e * B + c];
+        if (GENERIC) {
+#pragma unroll
+            for (int e = 0; e < M * M; e++)
+                if (!is_nan(Pf[e])) Ps[e] = Pf[e];
+        } else {
+            // P_SMOOTH(row, col, T) = Ps_final(row, col): cross-product sub-assignment, NewCase...m:125-127
+            bool rows[M], cols[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) { rows[i] = false; cols[i] = false; }
+#pragma unroll
+            for (int j = 0; j < M; j++)
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    if (!is_nan(Pf[IXM(i, j)])) { rows[i] = true; cols[j] = true; }
+#pragma unroll
+            for (int j = 0; j < M; j++)
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    if (rows[i] && cols[j]) Ps[IXM(i, j)] = Pf[IXM(i, j)];
+        }
+    }
+    store_vec<M>(a.S_SMOOTH, tT, B, c, Ss);
+    store_mat<M>(a.P_SMOOTH, tT, B, c, Ps);
+    if (GENERIC && a.u_opt_smooth) {
+        double z[kNpi];
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) z[k] = 0.0;
+        store_u(a.u_opt_smooth, a, tT, c, z);      // column T is never written :95,204
+    }
+    if (a.pinv_rank) a.pinv_rank[(size_t)tT * B + c] = -1;
+
+    int st_guard = 0, st_cap = 0, min_rank = M;
+    for (int k = T - 2; k >= 0; k--) {
+        const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
+        double Sp[M], Pp[M * M], Sm1[M], Pm1[M * M], u_in[kNpi];
+        load_vec<M>(a.S_PLUS, t, B, c, Sp);
+        load_mat<M>(a.P_PLUS, t, B, c, Pp);
+        load_vec<M>(a.S_MINUS, t1, B, c, Sm1);
+        load_mat<M>(a.P_MINUS, t1, B, c, Pm1);
+        load_u(a, t, su, u_in);
+
+        double J[M * M];
+        int rank = -1;
+        {
+            double A[M * M], PAt[M * M];
+            state_jacobians<M, FLIP>(p, u_in, Sp, A);          // :206
+            mat_mul_bt<M>(Pp, A, PAt);                         // P_PLUS * A'
+            if (GENERIC) {
+                bool bad = false;                              // :211
+#pragma unroll
+                for (int e = 0; e < M * M; e++) bad = bad || is_nonfinite(Pm1[e]);
+                if (bad) {
+#pragma unroll
+                    for (int e = 0; e < M * M; e++) J[e] = 0.0;
+                    st_guard = 1;
+                } else {
+                    double X[M * M];
+                    bool capped;
+                    rank = sym_pinv<M>(Pm1, X, &capped);       // :215
+                    mat_mul<M>(PAt, X, J);
+                    st_cap |= capped ? 1 : 0;
+                    min_rank = rank < min_rank ? rank : min_rank;
+                }
+            } else {
+                mrdivide<M>(PAt, Pm1, J);                      // NewCase...m:132
+            }
+        }
+        if (a.pinv_rank) a.pinv_rank[(size_t)t * B + c] = rank;
+
+        double Sn[M];
+        {
+            double dv[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) dv[i] = Ss[i] - Sm1[i];
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double acc = J[IXM(i, 0)] * dv[0];
+#pragma unroll
+                for (int j = 1; j < M; j++) acc = acc + J[IXM(i, j)] * dv[j];
+                Sn[i] = Sp[i] + acc;                           // :218
+            }
+        }
+        state_hard_margins<M>(p, Sn);                          // :221
+        {
+            double D[M * M], T1[M * M], T2[M * M];
+#pragma unroll
+            for (int e = 0; e < M * M; e++) D[e] = Pm1[e] - Ps[e];
+            mat_mul<M>(J, D, T1);
+            mat_mul_bt<M>(T1, J, T2);
+#pragma unroll
+            for (int e = 0; e < M * M; e++) Ps[e] = Pp[e] - T2[e];   // :223
+        }
+        if (GENERIC) symmetrize<M>(Ps);                        // :226
+#pragma unroll
+        for (int i = 0; i < M; i++) Ss[i] = Sn[i];
+        store_vec<M>(a.S_SMOOTH, t, B, c, Ss);
+        store_mat<M>(a.P_SMOOTH, t, B, c, Ps);
+        if (GENERIC && a.u_opt_smooth) {                       // :229
+            double sn_unused[M];
+            nlin_state_update<M, FLIP>(p, a.mf, u_in, Ss, sn_unused);
+            store_u(a.u_opt_smooth, a, t, c, u_in);
+        }
+    }
+    if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+}
+
+// ---------------------------------------------------------------------------
+// forward simulators
+// ---------------------------------------------------------------------------
+// Tools/SIalpha_Controlled.m:24-28 (+ NPICost.m:6-10 fused when J0/J1 are requested)
+__global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const int32_t *__restrict__ u_series,
+                                                   const double *__restrict__ u, const double *__restrict__ sp,
+                                                   const double *__restrict__ z, double *__restrict__ so,
+                                                   double *__restrict__ io, double *__restrict__ ao,
+                                                   double *__restrict__ J0, double *__restrict__ J1)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.B) return;
+    const int B = d.B;
+    auto g = [&](int f) { return sp[(size_t)f * B + c]; };
+    const int su = u_series ? u_series[c] : c;
+    double s = g(EPI_SIM_S0), i = g(EPI_SIM_I0), al = g(EPI_SIM_ALPHA0);
+    const double alpha_min = g(EPI_SIM_ALPHA_MIN), alpha_max = g(EPI_SIM_ALPHA_MAX), gamma = g(EPI_SIM_GAMMA);
+    const double b = g(EPI_SIM_B), beta = g(EPI_SIM_BETA), dt = g(EPI_SIM_DT);
+    const double s_std = g(EPI_SIM_S_STD), i_std = g(EPI_SIM_I_STD), a_std = g(EPI_SIM_ALPHA_STD);
+    double ga[kNpi], um[kNpi], w[kNpi];
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) { ga[k] = gamma * g(EPI_SIM_A + k); um[k] = g(EPI_SIM_U_MAX + k); w[k] = g(EPI_SIM_W + k); }
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int t = 0; t < d.K; t++) {
+        double uk[kNpi];
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) uk[k] = (k < d.n_npi) ? u[((size_t)t * d.n_npi + k) * d.Su + su] : 0.0;
+        double dot = ga[0] * (um[0] - uk[0]);
+#pragma unroll
+        for (int k = 1; k < kNpi; k++) dot = dot + ga[k] * (um[k] - uk[k]);
+        double z1 = 0.0, z2 = 0.0, z3 = 0.0;
+        if (d.noise) {
+            z1 = z[((size_t)t * 3 + 0) * B + c]; z2 = z[((size_t)t * 3 + 1) * B + c]; z3 = z[((size_t)t * 3 + 2) * B + c];
+        }
+        const double sn = fmax(0.0, fmin(1.0, s - dt * (al * s * i + z1 * s_std)));
+        const double in = fmax(0.0, fmin(1.0, i + dt * (al * s * i - beta * i + z2 * i_std)));
+        const double an = fmax(alpha_min, fmin(alpha_max, al + dt * (-gamma * al + gamma * b + dot + z3 * a_std)));
+        s = sn; i = in; al = an;
+        if (so) so[(size_t)t * B + c] = s;
+        if (io) io[(size_t)t * B + c] = i;
+        if (ao) ao[(size_t)t * B + c] = al;
+        if (d.with_cost) {
+            const double nc = s * i * al;
+            acc0 = (t == 0) ? nc : acc0 + nc;
+            // mean(weights(:).*inputs(:)) in column-major order: NPI index fastest
+#pragma unroll
+            for (int k = 0; k < kNpi; k++)
+                if (k < d.n_npi) {
+                    const double term = w[k] * uk[k];
+                    acc1 = (t == 0 && k == 0) ? term : acc1 + term;
+                }
+        }
+    }
+    if (d.with_cost) {
+        if (J0) J0[c] = acc0 / (double)d.K;
+        if (J1) J1[c] = acc1 / (double)((size_t)d.n_npi * (size_t)d.K);
+    }
+}
+
+struct SeirpRates { double ae, ai, kappa, rho, beta, mu, gamma; };
+EPI_DEV void seirp_rhs(const SeirpRates &r, const double (&y)[5], double (&f)[5])
+{
+    // SEIRP.m:27-31
+    f[0] = -r.ae * y[0] * y[1] - r.ai * y[0] * y[2] + r.gamma * y[3];
+    f[1] = r.ae * y[0] * y[1] + r.ai * y[0] * y[2] - r.kappa * y[1] - r.rho * y[1];
+    f[2] = r.kappa * y[1] - r.beta * y[2] - r.mu * y[2];
+    f[3] = r.beta * y[2] + r.rho * y[1] - r.gamma * y[3];
+    f[4] = r.mu * y[2];
+}
+__global__ __launch_bounds__(256) void seirp_sim(int B, int K, int par_steps, double dt, int saturated, int integrator,
+                                                 const double *__restrict__ par, const double *__restrict__ init,
+                                                 const double *__restrict__ sat, double *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    double y[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) { y[q] = init[(size_t)q * B + c]; out[(size_t)q * B + c] = y[q]; }
+    double b0 = 0, bs = 0, m0 = 0, ms = 0, sg = 1, i_0 = 0;
+    if (saturated) {
+        b0 = sat[(size_t)0 * B + c]; bs = sat[(size_t)1 * B + c]; m0 = sat[(size_t)2 * B + c];
+        ms = sat[(size_t)3 * B + c]; sg = sat[(size_t)4 * B + c]; i_0 = sat[(size_t)5 * B + c];
+    }
+    for (int t = 0; t < K - 1; t++) {
+        const size_t pt = (par_steps == 1) ? 0 : (size_t)t;
+        SeirpRates r;
+        r.ae = par[(pt * 7 + 0) * B + c]; r.ai = par[(pt * 7 + 1) * B + c]; r.kappa = par[(pt * 7 + 2) * B + c];
+        r.rho = par[(pt * 7 + 3) * B + c]; r.beta = par[(pt * 7 + 4) * B + c]; r.mu = par[(pt * 7 + 5) * B + c];
+        r.gamma = par[(pt * 7 + 6) * B + c];
+        if (saturated) {   // SEIRPSaturatedResource.m:27-29
+            const double h = (tanh((y[2] - i_0) / sg) + 1.0) / 2.0;
+            r.beta = (bs - b0) * h + b0;
+            r.mu = (ms - m0) * h + m0;
+        }
+        double yn[5];
+        if (integrator == 0) {      // explicit Euler, the reference's integrator: (rhs)*dt + y
+            double f[5];
+            seirp_rhs(r, y, f);
+#pragma unroll
+            for (int q = 0; q < 5; q++) yn[q] = f[q] * dt + y[q];
+        } else {                    // classical RK4 with the step's rates frozen (extension)
+            double k1[5], k2[5], k3[5], k4[5], yt[5];
+            seirp_rhs(r, y, k1);
+#pragma unroll
+            for (int q = 0; q < 5; q++) yt[q] = y[q] + 0.5 * dt * k1[q];
+            seirp_rhs(r, yt, k2);
+#pragma unroll
+            for (int q = 0; q < 5; q++) yt[q] = y[q] + 0.5 * dt * k2[q];
+            seirp_rhs(r, yt, k3);
+#pragma unroll
+            for (int q = 0; q < 5; q++) yt[q] = y[q] + dt * k3[q];
+            seirp_rhs(r, yt, k4);
+#pragma unroll
+            for (int q = 0; q < 5; q++) yn[q] = y[q] + (dt / 6.0) * (k1[q] + 2.0 * k2[q] + 2.0 * k3[q] + k4[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 5; q++) { y[q] = yn[q]; out[((size_t)(t + 1) * 5 + q) * B + c] = y[q]; }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static void set_err(char *err, const char *msg)
+{
+    if (err) { strncpy(err, msg, 255); err[255] = 0; }
+}
+static int hip_fail(char *err, hipError_t e, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "HIP error in %s: %s", what, hipGetErrorString(e));
+    set_err(err, buf);
+    return EPI_ERR_HIP;
+}
+
+struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, total; };
+static WsLayout ws_layout(const epi_batch_desc *d)
+{
+    const int m = MODEL_TABLE[d->model].m;
+    const size_t nS = (size_t)d->T * m * d->B * sizeof(double), nP = (size_t)d->T * m * m * d->B * sizeof(double);
+    WsLayout w{};
+    size_t off = 0;
+    auto take = [&](bool need, size_t n) { size_t o = off; if (need) off += (n + 255) & ~(size_t)255; return o; };
+    w.s_minus = take(!(d->out_mask & EPI_OUT_S_MINUS), nS);
+    w.s_plus = take(!(d->out_mask & EPI_OUT_S_PLUS), nS);
+    w.p_minus = take(!(d->out_mask & EPI_OUT_P_MINUS), nP);
+    w.p_plus = take(!(d->out_mask & EPI_OUT_P_PLUS), nP);
+    w.total = off;
+    return w;
+}
+
+template <int M, int FLIP, int GENERIC>
+static hipError_t launch_pair(const KArgs &ka, bool smooth, hipStream_t st)
+{
+    const int blocks = (ka.B + kWave - 1) / kWave;
+    const size_t shmem = (size_t)3 * ka.L * kWave * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void *)ekf_fwd<M, FLIP, GENERIC>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (smooth) {
+        hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+}  // namespace epi
+
+using namespace epi;
+
+extern "C" {
+
+int epi_abi_version(void) { return EPIEKF_ABI_VERSION; }
+
+const char *epi_status_string(int status)
+{
+    switch (status) {
+    case EPI_OK: return "ok";
+    case EPI_ERR_UNDEFINED_ORDER: return "Undefined order";
+    case EPI_ERR_Q_MISMATCH: return "Process noise covariance noise mismatch";
+    case EPI_ERR_R_MISMATCH: return "Observation noise covariance noise mismatch";
+    case EPI_ERR_OBS_TYPE: return "unknown observation type";
+    case EPI_ERR_BAD_ARG: return "bad argument";
+    case EPI_ERR_WORKSPACE: return "workspace too small";
+    case EPI_ERR_HIP: return "HIP runtime error";
+    case EPI_ERR_UNSUPPORTED: return "unsupported";
+    default: return "unknown status";
+    }
+}
+
+int epi_model_dim(int model) { return (model >= 0 && model < 6) ? MODEL_TABLE[model].m : -1; }
+
+int epi_ekf_validate(const epi_batch_desc *d, char *err)
+{
+    if (!d) { set_err(err, "NULL descriptor"); return EPI_ERR_BAD_ARG; }
+    if (d->abi_version != EPIEKF_ABI_VERSION) { set_err(err, "ABI version mismatch"); return EPI_ERR_BAD_ARG; }
+    if (d->model < 0 || d->model > 5) { set_err(err, "unknown model"); return EPI_ERR_BAD_ARG; }
+    if (d->B < 1 || d->T < 1 || d->Sx < 1 || d->Su < 1 || d->L < 1) { set_err(err, "B, T, Sx, Su, L must be >= 1"); return EPI_ERR_BAD_ARG; }
+    if (d->n_npi < 1 || d->n_npi > EPI_MAX_NPI) { set_err(err, "n_npi out of range 1..12"); return EPI_ERR_BAD_ARG; }
+    if (d->order != 1 && d->order != 2) { set_err(err, epi_status_string(EPI_ERR_UNDEFINED_ORDER)); return EPI_ERR_UNDEFINED_ORDER; }
+    const ModelInfo &mi = MODEL_TABLE[d->model];
+    if (!mi.obs_fixed && d->obs_type != EPI_OBS_NEWCASES && d->obs_type != EPI_OBS_TOTALCASES) {
+        set_err(err, epi_status_string(EPI_ERR_OBS_TYPE)); return EPI_ERR_OBS_TYPE;
+    }
+    if (d->q_mode != 0) { set_err(err, epi_status_string(EPI_ERR_Q_MISMATCH)); return EPI_ERR_Q_MISMATCH; }
+    if (d->r_mode != 0 && d->r_mode != 1) { set_err(err, epi_status_string(EPI_ERR_R_MISMATCH)); return EPI_ERR_R_MISMATCH; }
+    if (!mi.generic && d->r_mode != 0) {   // NewCase...m:31  R = R_v is used as a scalar
+        set_err(err, epi_status_string(EPI_ERR_R_MISMATCH)); return EPI_ERR_R_MISMATCH;
+    }
+    // three fp64 windows of L samples per lane must fit the CU's 160 KiB LDS
+    if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
+    return EPI_OK;
+}
+
+size_t epi_ekf_workspace_bytes(const epi_batch_desc *d)
+{
+    if (epi_ekf_validate(d, nullptr) != EPI_OK) return 0;
+    return ws_layout(d).total;
+}
+
+int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
+                       void *workspace, size_t workspace_bytes, void *stream, char *err)
+{
+    int rc = epi_ekf_validate(d, err);
+    if (rc != EPI_OK) return rc;
+    if (!in || !out) { set_err(err, "NULL inputs/outputs"); return EPI_ERR_BAD_ARG; }
+    const ModelInfo &mi = MODEL_TABLE[d->model];
+    if (!in->x || !in->u || !in->prm || !in->s_init || !in->Ps_init || !in->s_final || !in->Ps_final || !in->Q) {
+        set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG;
+    }
+    if (d->r_mode == 0 && !in->R_scalar) { set_err(err, "r_mode 0 needs R_scalar"); return EPI_ERR_BAD_ARG; }
+    if (d->r_mode == 1 && !in->R_series) { set_err(err, "r_mode 1 needs R_series"); return EPI_ERR_BAD_ARG; }
+    if (!in->x_series && d->Sx != d->B) { set_err(err, "identity x_series needs Sx == B"); return EPI_ERR_BAD_ARG; }
+    if (!in->u_series && d->Su != d->B) { set_err(err, "identity u_series needs Su == B"); return EPI_ERR_BAD_ARG; }
+    const WsLayout wl = ws_layout(d);
+    if (wl.total > 0 && (!workspace || workspace_bytes < wl.total)) {
+        set_err(err, epi_status_string(EPI_ERR_WORKSPACE)); return EPI_ERR_WORKSPACE;
+    }
+    const uint32_t om = d->out_mask;
+    auto sel = [&](uint32_t bit, double *p) -> double * { return (om & bit) ? p : nullptr; };
+    char *ws = (char *)workspace;
+    KArgs ka{};
+    ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode;
+    ka.mf.lo_is_zero = mi.lo_is_zero; ka.mf.phi_ge = mi.phi_ge; ka.mf.obs_clamp = mi.obs_clamp;
+    ka.mf.obs_type = mi.obs_fixed ? EPI_OBS_NEWCASES : d->obs_type;
+    ka.x_series = in->x_series; ka.u_series = in->u_series;
+    ka.x = in->x; ka.u = in->u; ka.R_series = in->R_series; ka.R_scalar = in->R_scalar; ka.prm = in->prm; ka.Q = in->Q;
+    if (!mi.flipped) {
+        ka.s_init = in->s_init; ka.Ps_init = in->Ps_init; ka.s_final = in->s_final; ka.Ps_final = in->Ps_final;
+    } else {   // Backward*.m:21-24
+        ka.s_init = in->s_final; ka.Ps_init = in->Ps_final; ka.s_final = in->s_init; ka.Ps_final = in->Ps_init;
+    }
+    const bool has_uos = mi.generic;
+    ka.S_MINUS = (om & EPI_OUT_S_MINUS) ? out->S_MINUS : (double *)(ws + wl.s_minus);
+    ka.S_PLUS = (om & EPI_OUT_S_PLUS) ? out->S_PLUS : (double *)(ws + wl.s_plus);
+    ka.P_MINUS = (om & EPI_OUT_P_MINUS) ? out->P_MINUS : (double *)(ws + wl.p_minus);
+    ka.P_PLUS = (om & EPI_OUT_P_PLUS) ? out->P_PLUS : (double *)(ws + wl.p_plus);
+    ka.u_opt = sel(EPI_OUT_U_OPT, out->u_opt);
+    ka.u_opt_smooth = has_uos ? sel(EPI_OUT_U_OPT_SMOOTH, out->u_opt_smooth) : nullptr;
+    ka.S_SMOOTH = sel(EPI_OUT_S_SMOOTH, out->S_SMOOTH);
+    ka.P_SMOOTH = sel(EPI_OUT_P_SMOOTH, out->P_SMOOTH);
+    ka.K_GAIN = sel(EPI_OUT_K_GAIN, out->K_GAIN);
+    ka.innovations = sel(EPI_OUT_INNOVATIONS, out->innovations);
+    ka.rho = sel(EPI_OUT_RHO, out->rho);
+    ka.pinv_rank = out->pinv_rank; ka.status = out->status;
+    {
+        struct { uint32_t bit; const void *p; const char *n; } chk[] = {
+            {EPI_OUT_U_OPT, out->u_opt, "u_opt"}, {EPI_OUT_S_MINUS, out->S_MINUS, "S_MINUS"},
+            {EPI_OUT_S_PLUS, out->S_PLUS, "S_PLUS"}, {EPI_OUT_S_SMOOTH, out->S_SMOOTH, "S_SMOOTH"},
+            {EPI_OUT_P_MINUS, out->P_MINUS, "P_MINUS"}, {EPI_OUT_P_PLUS, out->P_PLUS, "P_PLUS"},
+            {EPI_OUT_P_SMOOTH, out->P_SMOOTH, "P_SMOOTH"}, {EPI_OUT_K_GAIN, out->K_GAIN, "K_GAIN"},
+            {EPI_OUT_INNOVATIONS, out->innovations, "innovations"}, {EPI_OUT_RHO, out->rho, "rho"}};
+        for (auto &q : chk)
+            if ((om & q.bit) && !q.p) { char b[128]; snprintf(b, sizeof b, "output %s selected but NULL", q.n); set_err(err, b); return EPI_ERR_BAD_ARG; }
+        if (has_uos && (om & EPI_OUT_U_OPT_SMOOTH) && !out->u_opt_smooth) { set_err(err, "output u_opt_smooth selected but NULL"); return EPI_ERR_BAD_ARG; }
+    }
+    const bool smooth = (om & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && (om & EPI_OUT_U_OPT_SMOOTH)) ||
+                        out->pinv_rank || out->status;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    switch (d->model) {
+    case EPI_MODEL_SIA3: e = launch_pair<3, 0, 1>(ka, smooth, st); break;
+    case EPI_MODEL_SIA6: e = launch_pair<6, 0, 1>(ka, smooth, st); break;
+    case EPI_MODEL_SIA3_BWD: e = launch_pair<3, 1, 1>(ka, smooth, st); break;
+    case EPI_MODEL_SIA6_BWD: e = launch_pair<6, 1, 1>(ka, smooth, st); break;
+    default: e = launch_pair<6, 0, 0>(ka, smooth, st); break;
+    }
+    if (e != hipSuccess) return hip_fail(err, e, "kernel launch");
+    return EPI_OK;
+}
+
+int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, int device, char *err)
+{
+    int rc = epi_ekf_validate(d, err);
+    if (rc != EPI_OK) return rc;
+    if (!in || !out) { set_err(err, "NULL inputs/outputs"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    const int m = MODEL_TABLE[d->model].m, mm = m * m;
+    const size_t B = d->B, T = d->T;
+    std::vector<void *> allocs;
+    auto fail = [&](hipError_t ee, const char *what) { for (void *p : allocs) (void)hipFree(p); return hip_fail(err, ee, what); };
+    auto up = [&](const void *h, size_t bytes, const void **dev) -> hipError_t {
+        *dev = nullptr;
+        if (!h || bytes == 0) return hipSuccess;
+        void *p; hipError_t ee = hipMalloc(&p, bytes);
+        if (ee != hipSuccess) return ee;
+        allocs.push_back(p); *dev = p;
+        return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
+    };
+    epi_inputs din{};
+    epi_outputs dout{};
+#define UP(field, bytes) if ((e = up(in->field, (bytes), (const void **)&din.field)) != hipSuccess) return fail(e, "upload " #field)
+    UP(x_series, B * 4); UP(u_series, B * 4);
+    UP(x, T * d->Sx * 8); UP(u, T * d->n_npi * d->Su * 8);
+    if (d->r_mode == 1) { UP(R_series, T * d->Sx * 8); } else { UP(R_scalar, B * 8); }
+    UP(prm, (size_t)EPI_PRM_COUNT * B * 8);
+    UP(s_init, m * B * 8); UP(Ps_init, mm * B * 8); UP(s_final, m * B * 8); UP(Ps_final, mm * B * 8); UP(Q, mm * B * 8);
+#undef UP
+    struct O { uint32_t bit; double *const *host; double **dev; size_t bytes; };
+    const size_t nU = T * d->n_npi * B * 8, nS = T * m * B * 8, nP = T * mm * B * 8, n1 = T * B * 8;
+    O outs[] = {{EPI_OUT_U_OPT, &out->u_opt, &dout.u_opt, nU}, {EPI_OUT_U_OPT_SMOOTH, &out->u_opt_smooth, &dout.u_opt_smooth, nU},
+                {EPI_OUT_S_MINUS, &out->S_MINUS, &dout.S_MINUS, nS}, {EPI_OUT_S_PLUS, &out->S_PLUS, &dout.S_PLUS, nS},
+                {EPI_OUT_S_SMOOTH, &out->S_SMOOTH, &dout.S_SMOOTH, nS}, {EPI_OUT_P_MINUS, &out->P_MINUS, &dout.P_MINUS, nP},
+                {EPI_OUT_P_PLUS, &out->P_PLUS, &dout.P_PLUS, nP}, {EPI_OUT_P_SMOOTH, &out->P_SMOOTH, &dout.P_SMOOTH, nP},
+                {EPI_OUT_K_GAIN, &out->K_GAIN, &dout.K_GAIN, nS}, {EPI_OUT_INNOVATIONS, &out->innovations, &dout.innovations, n1},
+                {EPI_OUT_RHO, &out->rho, &dout.rho, n1}};
+    for (auto &o : outs)
+        if ((d->out_mask & o.bit) && *o.host) {
+            void *p; if ((e = hipMalloc(&p, o.bytes)) != hipSuccess) return fail(e, "hipMalloc output");
+            allocs.push_back(p); *o.dev = (double *)p;
+        }
+    if (out->pinv_rank) { void *p; if ((e = hipMalloc(&p, T * B * 4)) != hipSuccess) return fail(e, "hipMalloc"); allocs.push_back(p); dout.pinv_rank = (int32_t *)p; }
+    if (out->status) { void *p; if ((e = hipMalloc(&p, B * 4)) != hipSuccess) return fail(e, "hipMalloc"); allocs.push_back(p); dout.status = (int32_t *)p; }
+    void *ws = nullptr;
+    const size_t wsb = epi_ekf_workspace_bytes(d);
+    if (wsb) { if ((e = hipMalloc(&ws, wsb)) != hipSuccess) return fail(e, "hipMalloc workspace"); allocs.push_back(ws); }
+    rc = epi_ekf_run_device(d, &din, &dout, ws, wsb, nullptr, err);
+    if (rc != EPI_OK) { for (void *p : allocs) (void)hipFree(p); return rc; }
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "kernel execution");
+    for (auto &o : outs)
+        if (*o.dev && (e = hipMemcpy(*o.host, *o.dev, o.bytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
+    if (dout.pinv_rank && (e = hipMemcpy(out->pinv_rank, dout.pinv_rank, T * B * 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
+    if (dout.status && (e = hipMemcpy(out->status, dout.status, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
+    for (void *p : allocs) (void)hipFree(p);
+    return EPI_OK;
+}
+
+int epi_sialpha_sim_device(const epi_sim_desc *d, const int32_t *u_series, const double *u, const double *sp,
+                           const double *z, double *s, double *i, double *alpha, double *J0, double *J1,
+                           void *stream, char *err)
+{
+    if (!d || d->abi_version != EPIEKF_ABI_VERSION || d->B < 1 || d->K < 1 || d->Su < 1 || d->n_npi < 1 ||
+        d->n_npi > EPI_MAX_NPI || !u || !sp || (d->noise && !z) || (!u_series && d->Su != d->B)) {
+        set_err(err, "bad simulator descriptor"); return EPI_ERR_BAD_ARG;
+    }
+    const int blocks = (d->B + 255) / 256;
+    hipLaunchKernelGGL(sialpha_sim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, u_series, u, sp, z, s, i, alpha, J0, J1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "sialpha_sim launch");
+    return EPI_OK;
+}
+
+int epi_seirp_sim_device(int32_t B, int32_t K, int32_t par_steps, double dt, int32_t saturated, int32_t integrator,
+                         const double *par, const double *init, const double *sat, double *out, void *stream, char *err)
+{
+    if (B < 1 || K < 1 || !par || !init || !out || (saturated && !sat) || (par_steps != 1 && par_steps < K - 1) ||
+        (integrator != 0 && integrator != 1)) {
+        set_err(err, "bad SEIRP arguments"); return EPI_ERR_BAD_ARG;
+    }
+    const int blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(seirp_sim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, B, K, par_steps, dt, saturated, integrator, par, init, sat, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "seirp_sim launch");
+    return EPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference's Tools/ functions for the EKF/EKS hot path.
+
+Same names, argument order, shapes and error behaviour as the MATLAB functions; NumPy arrays stand in
+for MATLAB arrays (u: n_npi x T, x: 1 x T, S: m x T, P: m x m x T, K_GAIN: m x 1 x T).  Every call
+goes through the C ABI of libepiekf.so (epi_ekf_run_host) -- the same entry point the MEX gateway
+in matlab/ binds.  There is no CPU implementation behind these functions.
+
+  SIAlphaModelEKF                      Tools/SIAlphaModelEKF.m:1
+  SIAlphaModelEKFOptControlled         Tools/SIAlphaModelEKFOptControlled.m:1
+  SIAlphaModelBackwardEKF              Tools/SIAlphaModelBackwardEKF.m:1
+  SIAlphaModelBackwardEKFOptControlled Tools/SIAlphaModelBackwardEKFOptControlled.m:1
+  NewCaseEKFEstimatorWithOptimalNPI    Tools/NewCaseEKFEstimatorWithOptimalNPI.m:1 (10 outputs)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import layout as L
+from ._lib import EpiError
+
+__all__ = ["SIAlphaModelEKF", "SIAlphaModelEKFOptControlled", "SIAlphaModelBackwardEKF",
+           "SIAlphaModelBackwardEKFOptControlled", "NewCaseEKFEstimatorWithOptimalNPI",
+           "NewCaseEKFEstimatorWithOptimalNPI_codegen", "EpiError", "resolve_w"]
+
+# params fields each reference model actually reads (a missing one is a MATLAB run-time error there)
+_FIELDS3 = ("dt", "a", "b", "u_max", "alpha_min", "alpha_max", "gamma", "beta", "obs_type")
+_FIELDS = {
+    "SIAlphaModelEKF": _FIELDS3 + ("s_min", "i_min"),
+    "SIAlphaModelBackwardEKF": _FIELDS3,
+    "SIAlphaModelEKFOptControlled": _FIELDS3 + ("u_min", "sigma", "epsilon", "w"),
+    "SIAlphaModelBackwardEKFOptControlled": _FIELDS3 + ("u_min", "sigma", "epsilon", "w"),
+    "NewCaseEKFEstimatorWithOptimalNPI": _FIELDS3 + ("u_min", "sigma", "epsilon", "w"),
+    "NewCaseEKFEstimatorWithOptimalNPI_codegen": _FIELDS3[:-1] + ("u_min", "sigma", "epsilon", "w"),
+}
+
+
+def _get(params, k):
+    try:
+        return params[k] if isinstance(params, dict) else getattr(params, k)
+    except (KeyError, AttributeError):
+        raise KeyError(f'Reference to non-existent field "{k}".') from None
+
+
+def resolve_w(w, n: int) -> np.ndarray:
+    """params.w as the 6-state callbacks see it: `phi(kk)` is a LINEAR index into
+    `epsilon*w - gamma*s6*a` with `a` n x 1 (Tools/SIAlphaModelEKFOptControlled.m:49,107).
+    w n x 1 -> w(kk); w 1 x n (row, as testPrescribeXPRIZE02.m:56 passes) -> n x n matrix whose
+    linear indices 1..n are column 1 -> w(1) for every kk; w n x D -> w(kk,1); scalar -> scalar."""
+    w = np.asarray(w, dtype=np.float64)
+    if w.size == 1:
+        return np.full(n, float(w.reshape(-1)[0]))
+    if w.ndim == 1:
+        w = w.reshape(-1, 1)
+    if w.ndim != 2:
+        raise ValueError("params.w must be a scalar, vector or matrix")
+    if w.shape[0] == 1:
+        return np.full(n, float(w[0, 0]))
+    if w.shape[0] != n:
+        raise ValueError("Arrays have incompatible sizes for this operation.")
+    return np.ascontiguousarray(w[:, 0], dtype=np.float64)
+
+
+def _run(model, u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w, R_v, beta, gamma,
+         inv_monitor_len, order, device=0):
+    m = L.MODEL_DIM[model]
+    u = np.asarray(u, dtype=np.float64)
+    if u.ndim == 1:
+        u = u.reshape(-1, 1)
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 2 and x.shape[0] != 1:
+        raise ValueError("this engine implements the scalar-observation filter: size(x,1) must be 1")
+    x = x.reshape(-1)
+    T = x.shape[0]
+    nn = u.shape[0]
+    if u.shape[1] != T:
+        raise ValueError("size(u,2) must equal size(x,2)")
+    s_init = np.asarray(s_init, dtype=np.float64).reshape(-1)
+    if s_init.shape[0] != m:
+        raise ValueError(f"{model}: length(s_init) must be {m}")
+    for k in _FIELDS[model]:
+        _get(params, k)
+    prm = np.zeros((L.PRM_COUNT, 1))
+    six = m == 6
+    prm[L.PRM_DT] = _get(params, "dt"); prm[L.PRM_BETA] = _get(params, "beta"); prm[L.PRM_GAMMA] = _get(params, "gamma")
+    prm[L.PRM_B] = _get(params, "b")
+    prm[L.PRM_ALPHA_MIN] = _get(params, "alpha_min"); prm[L.PRM_ALPHA_MAX] = _get(params, "alpha_max")
+    if model == "SIAlphaModelEKF":
+        prm[L.PRM_S_MIN] = _get(params, "s_min"); prm[L.PRM_I_MIN] = _get(params, "i_min")
+    vec = lambda k: np.asarray(_get(params, k), dtype=np.float64).reshape(-1)
+    a, u_max = vec("a"), vec("u_max")
+    if a.shape[0] != nn or u_max.shape[0] != nn:
+        raise ValueError("Incorrect dimensions for matrix multiplication: params.a / params.u_max vs u")
+    prm[L.PRM_A:L.PRM_A + nn, 0] = a
+    prm[L.PRM_U_MAX:L.PRM_U_MAX + nn, 0] = u_max
+    if six:
+        prm[L.PRM_SIGMA] = _get(params, "sigma"); prm[L.PRM_EPSILON] = _get(params, "epsilon")
+        prm[L.PRM_U_MIN:L.PRM_U_MIN + nn, 0] = vec("u_min")
+        prm[L.PRM_W_EFF:L.PRM_W_EFF + nn, 0] = resolve_w(_get(params, "w"), nn)
+    prm[L.PRM_V_BAR] = float(np.asarray(v_bar).reshape(-1)[0])
+    prm[L.PRM_BETA_EKF] = float(beta); prm[L.PRM_GAMMA_EKF] = float(gamma)
+
+    # Q_w: GenericExtendedKalmanFilter.m:64-76
+    Q = np.asarray(Q_w, dtype=np.float64)
+    if Q.ndim <= 2 and Q.size == 1:
+        Qm = float(Q.reshape(-1)[0]) * np.eye(m)          # B*Q*B' with B = eye(m)
+    elif Q.ndim == 2 and Q.shape == (m, m):
+        Qm = Q
+    elif (Q.ndim == 3 and Q.shape[:2] == (m, m) and Q.shape[2] == T) or (Q.ndim <= 2 and Q.size == T and min(Q.shape) == 1):
+        raise EpiError(-8, "time-varying Q_w is valid in the reference but not supported by this engine")
+    else:
+        raise EpiError(-2, "Process noise covariance noise mismatch")
+    # R_v: GenericExtendedKalmanFilter.m:79-91
+    R = np.asarray(R_v, dtype=np.float64)
+    generic = not model.startswith("NewCase")
+    if R.size == 1:
+        r_mode, R_scalar, R_series = 0, np.array([float(R.reshape(-1)[0])]), None
+    elif generic and R.ndim <= 2 and min(R.shape) == 1 and R.size == T:
+        r_mode, R_scalar, R_series = 1, None, np.ascontiguousarray(R.reshape(T, 1))
+    else:
+        raise EpiError(-3, "Observation noise covariance noise mismatch")
+
+    col = lambda v, n: np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1)[:, None]) if np.asarray(v).size == n else None
+    fcol = lambda Mx: np.ascontiguousarray(np.asarray(Mx, dtype=np.float64).reshape(m, m).reshape(-1, order="F")[:, None])
+    si, sf = col(s_init, m), col(s_final, m)
+    if sf is None:
+        raise ValueError(f"length(s_final) must be {m}")
+    Pi, Pf, Qc = fcol(Ps_init), fcol(Ps_final), fcol(Qm)
+    xs = np.ascontiguousarray(x.reshape(T, 1))
+    us = np.ascontiguousarray(u.T.reshape(T, nn, 1))      # [T][n_npi][1] == MATLAB column-major n_npi x T
+
+    has_uos = generic
+    names = ["u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "P_MINUS", "P_PLUS", "P_SMOOTH",
+             "K_GAIN", "innovations", "rho"]
+    if not has_uos:
+        names.remove("u_opt_smooth")
+    mask = 0
+    for n_ in names:
+        mask |= L.OUT_BITS[n_]
+    desc = _lib.make_desc(model, 1, T, 1, 1, nn, int(inv_monitor_len), int(order), _get(params, "obs_type") if "obs_type" in _FIELDS[model] else "NEWCASES", r_mode, mask)
+    out = {n_: np.zeros((T, max(L.out_rows(n_, m, nn), 1), 1)) for n_ in names}
+    ins, outs = _lib.Inputs(), _lib.Outputs()
+    keep = [xs, us, prm, si, sf, Pi, Pf, Qc, R_scalar, R_series]
+    ins.x, ins.u, ins.prm = xs.ctypes.data, us.ctypes.data, prm.ctypes.data
+    ins.s_init, ins.s_final, ins.Ps_init, ins.Ps_final, ins.Q = si.ctypes.data, sf.ctypes.data, Pi.ctypes.data, Pf.ctypes.data, Qc.ctypes.data
+    ins.R_scalar = R_scalar.ctypes.data if R_scalar is not None else None
+    ins.R_series = R_series.ctypes.data if R_series is not None else None
+    for n_ in names:
+        setattr(outs, n_, out[n_].ctypes.data)
+    err = C.create_string_buffer(256)
+    rc = _lib.lib().epi_ekf_run_host(C.byref(desc), C.byref(ins), C.byref(outs), int(device), err)
+    _lib.check(rc, err)
+    del keep
+    S = lambda n_: np.asfortranarray(out[n_][:, :, 0].T)
+    P = lambda n_: np.asfortranarray(out[n_][:, :, 0].reshape(T, m, m).transpose(2, 1, 0))
+    res = {
+        "u_opt": S("u_opt"), "S_MINUS": S("S_MINUS"), "S_PLUS": S("S_PLUS"), "S_SMOOTH": S("S_SMOOTH"),
+        "P_MINUS": P("P_MINUS"), "P_PLUS": P("P_PLUS"), "P_SMOOTH": P("P_SMOOTH"),
+        "K_GAIN": np.asfortranarray(out["K_GAIN"][:, :, 0].T.reshape(m, 1, T)),
+        "innovations": out["innovations"][:, 0, 0].reshape(1, T).copy(),
+        "rho": out["rho"][:, 0, 0].reshape(T, 1).copy(),     # squeeze(rho): T x 1
+    }
+    if has_uos:
+        res["u_opt_smooth"] = S("u_opt_smooth")
+    return res
+
+
+def _eleven(r):
+    return (r["u_opt"], r["u_opt_smooth"], r["S_MINUS"], r["S_PLUS"], r["S_SMOOTH"], r["P_MINUS"], r["P_PLUS"],
+            r["P_SMOOTH"], r["K_GAIN"], r["innovations"], r["rho"])
+
+
+def SIAlphaModelEKF(u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w, R_v, beta, gamma,
+                    inv_monitor_len, order):
+    """[u_opt, u_opt_smooth, S_MINUS, S_PLUS, S_SMOOTH, P_MINUS, P_PLUS, P_SMOOTH, K_GAIN, innovations, rho]
+    = SIAlphaModelEKF(...)  -- Tools/SIAlphaModelEKF.m:1"""
+    return _eleven(_run("SIAlphaModelEKF", u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w,
+                        R_v, beta, gamma, inv_monitor_len, order))
+
+
+def SIAlphaModelEKFOptControlled(u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w, R_v, beta,
+                                 gamma, inv_monitor_len, order):
+    """Tools/SIAlphaModelEKFOptControlled.m:1 (NaN entries of u are replaced by the bang-bang control)."""
+    return _eleven(_run("SIAlphaModelEKFOptControlled", u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar,
+                        v_bar, Q_w, R_v, beta, gamma, inv_monitor_len, order))
+
+
+def SIAlphaModelBackwardEKF(u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w, R_v, beta, gamma,
+                            inv_monitor_len, order):
+    """Tools/SIAlphaModelBackwardEKF.m:1 (time-flipped 3-state filter)."""
+    return _eleven(_run("SIAlphaModelBackwardEKF", u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar,
+                        Q_w, R_v, beta, gamma, inv_monitor_len, order))
+
+
+def SIAlphaModelBackwardEKFOptControlled(u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w, R_v,
+                                         beta, gamma, inv_monitor_len, order):
+    """Tools/SIAlphaModelBackwardEKFOptControlled.m:1 (time-flipped 6-state filter)."""
+    return _eleven(_run("SIAlphaModelBackwardEKFOptControlled", u, x, params, s_init, Ps_init, s_final, Ps_final,
+                        w_bar, v_bar, Q_w, R_v, beta, gamma, inv_monitor_len, order))
+
+
+def NewCaseEKFEstimatorWithOptimalNPI(u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w, R_v,
+                                      beta, gamma, inv_monitor_len, order):
+    """[u_opt, S_MINUS, S_PLUS, S_SMOOTH, P_MINUS, P_PLUS, P_SMOOTH, K_GAIN, innovations, rho]
+    -- Tools/NewCaseEKFEstimatorWithOptimalNPI.m:1 (Tools/ output order, 10 outputs)."""
+    r = _run("NewCaseEKFEstimatorWithOptimalNPI", u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar,
+             Q_w, R_v, beta, gamma, inv_monitor_len, order)
+    return (r["u_opt"], r["S_MINUS"], r["S_PLUS"], r["S_SMOOTH"], r["P_MINUS"], r["P_PLUS"], r["P_SMOOTH"],
+            r["K_GAIN"], r["innovations"], r["rho"])
+
+
+def NewCaseEKFEstimatorWithOptimalNPI_codegen(u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, Q_w,
+                                              R_v, beta, gamma, inv_monitor_len, order):
+    """[u_opt, S_MINUS, S_PLUS, P_MINUS, P_PLUS, K_GAIN, S_SMOOTH, P_SMOOTH, innovations, rho]
+    -- MatlabCodeGenerator/NewCaseEKFEstimatorWithOptimalNPI.m:1 (codegen output order; observation
+    clamp is the identity and the observation is always NEWCASES there)."""
+    r = _run("NewCaseEKFEstimatorWithOptimalNPI_codegen", u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar,
+             v_bar, Q_w, R_v, beta, gamma, inv_monitor_len, order)
+    return (r["u_opt"], r["S_MINUS"], r["S_PLUS"], r["P_MINUS"], r["P_PLUS"], r["K_GAIN"], r["S_SMOOTH"],
+            r["P_SMOOTH"], r["innovations"], r["rho"])

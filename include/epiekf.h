@@ -1,0 +1,191 @@
+/*
+ * epiekf.h -- C ABI of libepiekf.so: the MI355X (gfx950) ensemble engine for the
+ * reference's per-region EKF/EKS hot path.
+ *
+ * Drop-in boundary.  The reference's interface for this path is a family of
+ * MATLAB functions with one signature (Tools/SIAlphaModelEKF.m:1,
+ * Tools/SIAlphaModelEKFOptControlled.m:1, Tools/SIAlphaModelBackwardEKF.m:1,
+ * Tools/SIAlphaModelBackwardEKFOptControlled.m:1,
+ * Tools/NewCaseEKFEstimatorWithOptimalNPI.m:1):
+ *
+ *   [u_opt, u_opt_smooth, S_MINUS, S_PLUS, S_SMOOTH, P_MINUS, P_PLUS, P_SMOOTH,
+ *    K_GAIN, innovations, rho] = F(u, x, params, s_init, Ps_init, s_final,
+ *    Ps_final, w_bar, v_bar, Q_w, R_v, beta, gamma, inv_monitor_len, order)
+ *
+ * A MEX gateway / ctypes stub binds exactly the entry points below (see
+ * INTEGRATION.md).  One call runs B independent filter chains ("chains" =
+ * region x cost-factor x Monte-Carlo member); B = 1 with the identity series
+ * maps reproduces one reference call, and with B = 1 every array below has
+ * exactly MATLAB's column-major memory layout (u: n_npi x T, S: m x T,
+ * P: m x m x T), so a gateway can pass mxGetPr() pointers straight through.
+ *
+ * Memory layout (batched, "SoA"): time-major, then row, then chain:
+ *   x         [T][Sx]            observations; NaN = missing (GenericEKF.m:122)
+ *   u         [T][n_npi][Su]     controls; NaN = "choose optimally" (OptControlled.m:49-58)
+ *   R_series  [T][Sx]            R_v given as 1xT vector (fixed_R = false, GenericEKF.m:82-85)
+ *   R_scalar  [B]                R_v given as a scalar   (fixed_R = true,  GenericEKF.m:79-81)
+ *   prm       [EPI_PRM_COUNT][B] params struct + v_bar/beta/gamma (epiekf_layout.h)
+ *   s_init    [m][B]   Ps_init [m*m][B]   s_final [m][B]   Ps_final [m*m][B]   Q [m*m][B]
+ *   outputs   S_* [T][m][B], P_* [T][m*m][B] (element e = row + m*col), K_GAIN [T][m][B],
+ *             u_opt* [T][n_npi][B], innovations/rho [T][B]
+ * Chain c reads column x_series[c] of x / R_series and column u_series[c] of u
+ * (NULL map = identity, then Sx resp. Su must equal B): the Pareto sweep's 250
+ * cost factors of one region share that region's series
+ * (Tools/TrainPredictPrescribeNPI.m:421-460).
+ *
+ * Ownership / threading / errors: the caller owns every buffer; the library
+ * never frees or retains caller memory; calls are re-entrant and keep no global
+ * state; all device work of a call is enqueued on the caller's stream.  Return
+ * value 0 or a negative epi_status; `err` (256 bytes, may be NULL) receives the
+ * reference's own error() text for the four reference errors.
+ */
+#ifndef EPIEKF_H
+#define EPIEKF_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "epiekf_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EPIEKF_ABI_VERSION 1
+
+/* which reference function the chain runs */
+typedef enum epi_model {
+    EPI_MODEL_SIA3 = 0,          /* Tools/SIAlphaModelEKF.m                      (m = 3) */
+    EPI_MODEL_SIA6 = 1,          /* Tools/SIAlphaModelEKFOptControlled.m         (m = 6) */
+    EPI_MODEL_SIA3_BWD = 2,      /* Tools/SIAlphaModelBackwardEKF.m              (m = 3) */
+    EPI_MODEL_SIA6_BWD = 3,      /* Tools/SIAlphaModelBackwardEKFOptControlled.m (m = 6) */
+    EPI_MODEL_NEWCASE6 = 4,      /* Tools/NewCaseEKFEstimatorWithOptimalNPI.m    (m = 6) */
+    EPI_MODEL_NEWCASE6_CODEGEN = 5 /* MatlabCodeGenerator/NewCaseEKFEstimatorWithOptimalNPI.m */
+} epi_model;
+
+typedef enum epi_obs_type {      /* params.obs_type, Tools/SIAlphaModelEKF.m:52-58 */
+    EPI_OBS_NEWCASES = 0,
+    EPI_OBS_TOTALCASES = 1
+} epi_obs_type;
+
+typedef enum epi_status {
+    EPI_OK = 0,
+    EPI_ERR_UNDEFINED_ORDER = -1, /* 'Undefined order'  GenericExtendedKalmanFilter.m:111,151 */
+    EPI_ERR_Q_MISMATCH = -2,      /* 'Process noise covariance noise mismatch'      :75 */
+    EPI_ERR_R_MISMATCH = -3,      /* 'Observation noise covariance noise mismatch'  :90 */
+    EPI_ERR_OBS_TYPE = -4,        /* 'unknown observation type'  SIAlphaModelEKF.m:57,87 */
+    EPI_ERR_BAD_ARG = -5,         /* NULL / size / range error in the descriptor */
+    EPI_ERR_WORKSPACE = -6,       /* workspace too small */
+    EPI_ERR_HIP = -7,             /* HIP runtime failure (no device, launch error, ...) */
+    EPI_ERR_UNSUPPORTED = -8
+} epi_status;
+
+/* output selection bits, in the order of the reference's output list */
+typedef enum epi_out {
+    EPI_OUT_U_OPT = 1 << 0,
+    EPI_OUT_U_OPT_SMOOTH = 1 << 1,
+    EPI_OUT_S_MINUS = 1 << 2,
+    EPI_OUT_S_PLUS = 1 << 3,
+    EPI_OUT_S_SMOOTH = 1 << 4,
+    EPI_OUT_P_MINUS = 1 << 5,
+    EPI_OUT_P_PLUS = 1 << 6,
+    EPI_OUT_P_SMOOTH = 1 << 7,
+    EPI_OUT_K_GAIN = 1 << 8,
+    EPI_OUT_INNOVATIONS = 1 << 9,
+    EPI_OUT_RHO = 1 << 10,
+    EPI_OUT_ALL = (1 << 11) - 1
+} epi_out;
+
+typedef struct epi_batch_desc {
+    int32_t abi_version;  /* EPIEKF_ABI_VERSION */
+    int32_t model;        /* epi_model */
+    int32_t B;            /* chains */
+    int32_t T;            /* time samples  = size(x, 2) */
+    int32_t Sx, Su;       /* distinct observation / control series */
+    int32_t n_npi;        /* size(u, 1), 1..EPI_MAX_NPI */
+    int32_t L;            /* inv_monitor_len */
+    int32_t order;        /* 1 or 2 (2 is accepted: all SI-alpha Hessian callbacks are zero,
+                             Tools/SIAlphaModelEKF.m:92-109) */
+    int32_t obs_type;     /* epi_obs_type */
+    int32_t r_mode;       /* 0: R_scalar[B] (scalar R_v, adaptive when beta != 1); 1: R_series */
+    int32_t q_mode;       /* 0: fixed per-chain m x m Q_w (the only form the reference's callers use) */
+    uint32_t out_mask;    /* epi_out bits: which outputs are written */
+    int32_t reserved;
+} epi_batch_desc;
+
+typedef struct epi_inputs {
+    const int32_t *x_series; /* [B] or NULL */
+    const int32_t *u_series; /* [B] or NULL */
+    const double *x, *u, *R_series, *R_scalar, *prm;
+    const double *s_init, *Ps_init, *s_final, *Ps_final, *Q;
+} epi_inputs;
+
+typedef struct epi_outputs {
+    double *u_opt, *u_opt_smooth;
+    double *S_MINUS, *S_PLUS, *S_SMOOTH;
+    double *P_MINUS, *P_PLUS, *P_SMOOTH;
+    double *K_GAIN, *innovations, *rho;
+    /* extras (not reference outputs; may be NULL) */
+    int32_t *pinv_rank;   /* [T][B] rank kept by pinv at smoother step k (-1: not executed / guard) */
+    int32_t *status;      /* [B] per-chain flags: bit0 non-finite P_MINUS guard hit (GenericEKF.m:211),
+                             bit1 Jacobi sweep cap reached, bits 8.. minimum pinv rank seen */
+} epi_outputs;
+
+/* ---- EKF / EKS ---------------------------------------------------------- */
+int epi_model_dim(int model);                                   /* 3, 6 or -1 */
+int epi_ekf_validate(const epi_batch_desc *d, char *err);       /* descriptor checks only, no GPU */
+size_t epi_ekf_workspace_bytes(const epi_batch_desc *d);        /* device scratch a run needs */
+
+/* All pointers in `in`/`out`/`workspace` are DEVICE pointers on the current HIP
+ * device; `stream` is a hipStream_t (NULL = default stream).  Asynchronous:
+ * returns after enqueueing.  Outputs not selected in out_mask may be NULL. */
+int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
+                       void *workspace, size_t workspace_bytes, void *stream, char *err);
+
+/* Same call on HOST pointers: allocates device buffers, copies in, runs, copies
+ * the selected outputs back and synchronises (what a MEX gateway calls). */
+int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
+                     int device, char *err);
+
+/* ---- forward simulators and cost (Tools/SIalpha_Controlled.m, SEIRP.m, NPICost.m) ---- */
+typedef struct epi_sim_desc {
+    int32_t abi_version;
+    int32_t B;        /* chains */
+    int32_t K;        /* steps */
+    int32_t Su;       /* distinct control series */
+    int32_t n_npi;
+    int32_t noise;    /* 0: noise-free; 1: z given [K][3][B] standard normal draws */
+    int32_t with_cost;/* 1: also J0/J1 of NPICost over the simulated span */
+    int32_t reserved;
+} epi_sim_desc;
+
+/* SIalpha_Controlled.m:1-32 batched.  sp [EPI_SIM_PRM_COUNT][B]; u [K][n_npi][Su];
+ * outputs s,i,alpha [K][B] (initial sample dropped, :30-32); J0,J1 [B] when with_cost:
+ * J0 = mean(s.*i.*alpha), J1 = mean(weights.*u) with weights [n_npi][B] constant over time. */
+enum {
+    EPI_SIM_S0 = 0, EPI_SIM_I0, EPI_SIM_ALPHA0, EPI_SIM_ALPHA_MIN, EPI_SIM_ALPHA_MAX, EPI_SIM_GAMMA,
+    EPI_SIM_B, EPI_SIM_BETA, EPI_SIM_S_STD, EPI_SIM_I_STD, EPI_SIM_ALPHA_STD, EPI_SIM_DT,
+    EPI_SIM_A = 12,      /* a(1:12)     */
+    EPI_SIM_U_MAX = 24,  /* u_max(1:12) */
+    EPI_SIM_W = 36,      /* NPICost weights(1:12), constant over time */
+    EPI_SIM_PRM_COUNT = 48
+};
+int epi_sialpha_sim_device(const epi_sim_desc *d, const int32_t *u_series, const double *u,
+                           const double *sp, const double *z, double *s, double *i, double *alpha,
+                           double *J0, double *J1, void *stream, char *err);
+
+/* SEIRP.m:1-32 / SEIRPSaturatedResource.m:1-38 batched: par [K][7][B] per-step parameter arrays in the
+ * order alpha_e, alpha_i, kappa, rho, beta, mu, gamma (or constant-in-time: par [1][7][B], par_steps=1);
+ * init [5][B] = s0,e0,i0,r0,p0; out [K][5][B].  saturated != 0: sat [6][B] = beta_0,beta_s,mu_0,mu_s,
+ * sigma,i_0 and par rows 4,5 (beta, mu) are ignored.  integrator: 0 = explicit Euler (the reference,
+ * parity), 1 = classical RK4 (extension; no reference oracle). */
+int epi_seirp_sim_device(int32_t B, int32_t K, int32_t par_steps, double dt, int32_t saturated,
+                         int32_t integrator, const double *par, const double *init, const double *sat,
+                         double *out, void *stream, char *err);
+
+const char *epi_status_string(int status);
+int epi_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
