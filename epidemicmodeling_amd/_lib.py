@@ -51,6 +51,22 @@ class SimDesc(C.Structure):
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same SONAME as
+    /opt/rocm's); device pointers and streams handed to libepiekf.so come from torch, so the library
+    must bind to torch's runtime, whichever of the two is loaded first.  Loading torch's copy by path
+    here (no `import torch` needed) makes the dynamic linker resolve libepiekf.so's NEEDED
+    libamdhip64.so.7 to it, and a later `import torch` reuses the same mapping.  Without torch in the
+    environment (e.g. a MEX host) the system runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libepiekf.so; raises if absent (build it with __graft_entry__.build())."""
     global _lib
@@ -58,6 +74,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not found: build the HIP library first "
                               "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+        _preload_torch_hip_runtime()
         h = C.CDLL(LIB_PATH)
         h.epi_abi_version.restype = C.c_int
         h.epi_status_string.restype = C.c_char_p
