@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the EKF/EKS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (forward EKF kernel + backward EKS kernel) over one batch of
+synthetic input: BASELINE.json's headline sweep, SIAlphaModelEKFOptControlled over 300 regions x 250
+NPI-cost weights x (400 observed + 120 horizon) days = 75 000 chains x 520 days = 39.0 M region-day
+EKF steps, all 11 reference outputs written (1376 algorithmic bytes per region-day step).  Inputs are
+resident in HBM before the timed region.  With N > 1 every rank (one process per GPU, RCCL) filters its
+own 75 000-chain shard of a 300*N-region sweep (weak scaling; chains are independent, no data-path
+collective) and the per-chain end-of-history smoothed states are gathered to rank 0 at the end of
+every step -- the path's only collective.
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_STEP_FULL = {3: 632, 6: 1376}      # inputs 112 B + all reference outputs
+# split of the algorithmic bytes by kernel (DESIGN.md "Algorithmic bytes"): forward kernel reads
+# x,u,R (112 B) and writes S-,S+,P-,P+,K,innov,rho,u_opt; smoother writes S_s,P_s,u_opt_smooth
+BYTES_FWD = {3: 112 + 8 * (3 + 3 + 9 + 9 + 3 + 1 + 1 + 12), 6: 112 + 8 * (6 + 6 + 36 + 36 + 6 + 1 + 1 + 12)}
+BYTES_BWD = {3: 8 * (3 + 9 + 12), 6: 8 * (6 + 36 + 12)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--regions", type=int, default=300)
+    ap.add_argument("--eps", type=int, default=250)
+    ap.add_argument("--t-hist", type=int, default=400)
+    ap.add_argument("--horizon", type=int, default=120)
+    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg3", "cfg5"])
+    ap.add_argument("--outputs", default="all", choices=["all", "reduced"],
+                    help="reduced = u_opt_smooth + S_SMOOTH only (what TrainPredictPrescribeNPI.m:460-493 consumes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-chains", type=int, default=0, help="0 = sized for ~15 s")
+    return ap.parse_args()
+
+
+def make_workload(args, rank):
+    from epidemicmodeling_amd import synth
+    if args.workload == "cfg4":
+        w = synth.make_cfg4(args.regions, args.eps, args.t_hist, args.horizon, region_offset=rank * args.regions)
+        name = (f"cfg4: SIAlphaModelEKFOptControlled sweep, {args.regions} regions x {args.eps} cost weights x "
+                f"({args.t_hist}+{args.horizon}) days")
+    elif args.workload == "cfg3":
+        w = synth.make_cfg3(args.regions, args.t_hist, region_offset=rank * args.regions)
+        name = f"cfg3: SIAlphaModelEKF, {args.regions} regions x {args.t_hist} days"
+    else:
+        w = synth.make_cfg5(args.regions, args.eps, args.t_hist)
+        name = f"cfg5: 3-state MC-EKS, {args.regions} regions x {args.eps} draws x {args.t_hist} days"
+    return w, name
+
+
+def cpu_baseline(w, args):
+    """The CPU oracle (C restatement of Tools/*.m, MATLAB unavailable) timed on this host's cores over a
+    bounded sample of the same workload: every k-th chain, all days, all outputs."""
+    from tests import helpers as H
+    cores = os.cpu_count() or 1
+    n = args.cpu_sample_chains
+    if n <= 0:
+        # ~20 k steps/s/core for the 6-state filter+smoother, ~80 k for the 3-state one: aim at ~15 s
+        rate = (20e3 if w.m == 6 else 80e3) * cores
+        n = int(max(cores * 4, min(w.B, rate * 15.0 / w.T)))
+    idx = np.linspace(0, w.B - 1, n).astype(np.int64)
+    ws = w.select(idx)
+    H.oracle_batch(w.select(idx[: max(cores, 8)]), n_threads=cores)     # warm the library / threads
+    t0 = time.perf_counter()
+    H.oracle_batch(ws, n_threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": ws.B * ws.T / dt, "unit": "region-day EKF steps/s", "cores": cores, "kind": "port",
+            "sample": f"{ws.B} of {w.B} chains (every {max(1, w.B // n)}th) x {ws.T} days, all 11 outputs, "
+                      f"OpenMP over chains, {dt:.1f} s; C restatement of Tools/*.m (MATLAB unavailable)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from epidemicmodeling_amd import batch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, wname = make_workload(args, rank)
+    m = w.m
+    outputs = None if args.outputs == "all" else ["u_opt_smooth", "S_SMOOTH"]
+    dw = batch.DeviceWorkload(w, dev)
+    runner = batch.EkfRunner(dw, outputs=outputs, extras=False)
+    steps_per_pass = w.B * w.T
+    t_hist_idx = w.meta.get("T_hist", w.T) - 1
+
+    def one_step(events=None):
+        if events is None:
+            runner.run()
+        else:
+            e0, e1, e2 = events
+            e0.record(); runner.run(phase=1); e1.record(); runner.run(phase=2); e2.record()
+        if world > 1:
+            # end-of-sweep result gather (per-chain smoothed state at the last observed day) to rank 0
+            batch.gather_to_root(runner.out["S_SMOOTH"][t_hist_idx].contiguous())
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize(dev)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(evs[k])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ms_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
+    ms_bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    if rank == 0:
+        total_steps = steps_per_pass * world * args.steps
+        value = total_steps / elapsed
+        full = args.outputs == "all"
+        b_fwd = BYTES_FWD[m] if full else 112
+        b_bwd = BYTES_BWD[m] if full else 8 * (m + 12)
+        dom_is_bwd = ms_bwd >= ms_fwd
+        dom_ms = ms_bwd if dom_is_bwd else ms_fwd
+        dom_bytes = (b_bwd if dom_is_bwd else b_fwd) * steps_per_pass
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        step_gbs = (b_fwd + b_bwd) * steps_per_pass / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
+        res = {
+            "metric": "region-day EKF steps/sec (300 regions x 400 days x 250 costs)",
+            "value": value, "unit": "region-day EKF steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs,
+                       "region_day_steps_per_pass_per_gpu": steps_per_pass,
+                       "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
+                       "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather to rank 0"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "eks_bwd" if dom_is_bwd else "ekf_fwd",
+                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes},
+            "kernels": {"ekf_fwd_ms": ms_fwd, "eks_bwd_ms": ms_bwd,
+                        "ekf_fwd_GBs": b_fwd * steps_per_pass / (ms_fwd * 1e-3) / 1e9,
+                        "eks_bwd_GBs": b_bwd * steps_per_pass / (ms_bwd * 1e-3) / 1e9,
+                        "whole_step_GBs": step_gbs, "whole_step_frac_of_hbm_peak": step_gbs / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(w, args)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,7 @@ class EpiError(RuntimeError):
 class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "model", "B", "T", "Sx", "Su", "n_npi", "L", "order",
                                           "obs_type", "r_mode", "q_mode")] + [
-        ("out_mask", C.c_uint32), ("reserved", C.c_int32)]
+        ("out_mask", C.c_uint32), ("phase", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -118,5 +118,5 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask)
         d.obs_type = L.OBS_IDS.get(obs_type, 99)   # unknown strings reach the library's own check
     else:
         d.obs_type = int(obs_type)
-    d.r_mode, d.q_mode, d.out_mask, d.reserved = int(r_mode), 0, int(out_mask), 0
+    d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), 0, int(out_mask), 0
     return d

@@ -89,9 +89,11 @@ class EkfRunner:
         self.outs.pinv_rank = _ptr(self.pinv_rank)
         self.outs.status = _ptr(self.status)
 
-    def run(self, stream=None):
-        """Enqueue forward + backward kernels on `stream` (default: torch's current stream)."""
+    def run(self, stream=None, phase: int = 0):
+        """Enqueue forward + backward kernels on `stream` (default: torch's current stream).
+        phase 1 / 2 enqueue only the forward / only the smoother kernel (per-kernel timing)."""
         st = torch.cuda.current_stream(self.dw.device) if stream is None else stream
+        self.desc.phase = phase
         rc = _lib.lib().epi_ekf_run_device(C.byref(self.desc), C.byref(self.ins), C.byref(self.outs),
                                            _ptr(self.ws), self.ws_bytes, C.c_void_p(st.cuda_stream), self.err)
         _lib.check(rc, self.err)

@@ -531,16 +531,21 @@ static WsLayout ws_layout(const epi_batch_desc *d)
 }
 
 template <int M, int FLIP, int GENERIC>
-static hipError_t launch_pair(const KArgs &ka, bool smooth, hipStream_t st)
+static hipError_t launch_pair(const KArgs &ka, bool forward, bool smooth, hipStream_t st)
 {
     const int blocks = (ka.B + kWave - 1) / kWave;
     const size_t shmem = (size_t)3 * ka.L * kWave * sizeof(double);
-    hipError_t e = hipFuncSetAttribute((const void *)ekf_fwd<M, FLIP, GENERIC>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (forward) {
+        if (shmem > 64u * 1024u) {   // above the default dynamic-LDS limit
+            e = hipFuncSetAttribute((const void *)ekf_fwd<M, FLIP, GENERIC>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     if (smooth) {
         hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
         e = hipGetLastError();
@@ -592,6 +597,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
         set_err(err, epi_status_string(EPI_ERR_R_MISMATCH)); return EPI_ERR_R_MISMATCH;
     }
     // three fp64 windows of L samples per lane must fit the CU's 160 KiB LDS
+    if (d->phase < 0 || d->phase > 2) { set_err(err, "phase must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
 }
@@ -658,16 +664,18 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
             if ((om & q.bit) && !q.p) { char b[128]; snprintf(b, sizeof b, "output %s selected but NULL", q.n); set_err(err, b); return EPI_ERR_BAD_ARG; }
         if (has_uos && (om & EPI_OUT_U_OPT_SMOOTH) && !out->u_opt_smooth) { set_err(err, "output u_opt_smooth selected but NULL"); return EPI_ERR_BAD_ARG; }
     }
-    const bool smooth = (om & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && (om & EPI_OUT_U_OPT_SMOOTH)) ||
-                        out->pinv_rank || out->status;
+    const bool forward = (d->phase != 2);
+    const bool smooth = (d->phase != 1) &&
+                        ((om & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && (om & EPI_OUT_U_OPT_SMOOTH)) ||
+                         out->pinv_rank || out->status);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     switch (d->model) {
-    case EPI_MODEL_SIA3: e = launch_pair<3, 0, 1>(ka, smooth, st); break;
-    case EPI_MODEL_SIA6: e = launch_pair<6, 0, 1>(ka, smooth, st); break;
-    case EPI_MODEL_SIA3_BWD: e = launch_pair<3, 1, 1>(ka, smooth, st); break;
-    case EPI_MODEL_SIA6_BWD: e = launch_pair<6, 1, 1>(ka, smooth, st); break;
-    default: e = launch_pair<6, 0, 0>(ka, smooth, st); break;
+    case EPI_MODEL_SIA3: e = launch_pair<3, 0, 1>(ka, forward, smooth, st); break;
+    case EPI_MODEL_SIA6: e = launch_pair<6, 0, 1>(ka, forward, smooth, st); break;
+    case EPI_MODEL_SIA3_BWD: e = launch_pair<3, 1, 1>(ka, forward, smooth, st); break;
+    case EPI_MODEL_SIA6_BWD: e = launch_pair<6, 1, 1>(ka, forward, smooth, st); break;
+    default: e = launch_pair<6, 0, 0>(ka, forward, smooth, st); break;
     }
     if (e != hipSuccess) return hip_fail(err, e, "kernel launch");
     return EPI_OK;

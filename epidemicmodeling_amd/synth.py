@@ -106,18 +106,19 @@ def load_trained_params():
     return {k: d[k] for k in d.files}
 
 
-def make_regions(n_regions: int, seed: int = 20210207):
+def make_regions(n_regions: int, seed: int = 20210207, region_offset: int = 0):
     """Regions r -> row r mod 235 of the trained-parameter table; wrapped rows get `a`
     jittered by 1 + 0.1*U(-1,1) (Philox stream `seed`)."""
     tp = load_trained_params()
     n_real = tp["N_population"].shape[0]
-    idx = np.arange(n_regions) % n_real
+    gid = np.arange(n_regions) + region_offset        # global region id (rank r of a multi-GPU sweep: r*n_regions..)
+    idx = gid % n_real
     N = tp["N_population"][idx].astype(np.float64)
     a = tp["coef_2"][idx].astype(np.float64).copy()
     b = tp["coef0_2"][idx].astype(np.float64).copy()
-    rng = np.random.Generator(np.random.Philox(seed))
+    rng = np.random.Generator(np.random.Philox(seed + region_offset))
     jit = 1.0 + 0.1 * rng.uniform(-1.0, 1.0, size=(n_regions, NUM_NPI))
-    wrapped = np.arange(n_regions) >= n_real
+    wrapped = gid >= n_real
     a[wrapped] *= jit[wrapped]
     return {"N": N, "a": a, "b": b, "names": tp["names"][idx]}
 
@@ -223,12 +224,12 @@ def _filter_setup3(regions, I0):
     return s_init, Q, P0
 
 
-def make_cfg3(n_regions: int = 300, T: int = 400) -> Workload:
+def make_cfg3(n_regions: int = 300, T: int = 400, region_offset: int = 0) -> Workload:
     """BASELINE config 3: SIAlphaModelEKF over `n_regions` regions x T days (round-2 call:
     a, b from the trained table, u = NPI history, R_v 1xT)."""
-    reg = make_regions(n_regions)
-    u = make_npi_history(n_regions, T)
-    obs = simulate_observations(reg, u)
+    reg = make_regions(n_regions, region_offset=region_offset)
+    u = make_npi_history(n_regions, T, seed=1 + region_offset)
+    obs = simulate_observations(reg, u, seed=2 + region_offset)
     s_init, Q, P0 = _filter_setup3(reg, obs["I0"])
     prm = _base_prm(n_regions)
     prm[L.PRM_S_MIN] = MIN_CASES / reg["N"]
@@ -249,13 +250,14 @@ def epsilon_grid(n: int = 250) -> np.ndarray:
     return np.concatenate([np.logspace(-12.0, -eps, h), np.linspace(eps, 1 - eps, n - h)])
 
 
-def make_cfg4(n_regions: int = 300, n_eps: int = 250, T_hist: int = 400, horizon: int = 120) -> Workload:
+def make_cfg4(n_regions: int = 300, n_eps: int = 250, T_hist: int = 400, horizon: int = 120,
+              region_offset: int = 0) -> Workload:
     """BASELINE config 4: SIAlphaModelEKFOptControlled Pareto sweep, regions x epsilon chains over
     T_hist observed days + `horizon` days with x = NaN and u = NaN (TrainPredictPrescribeNPI.m:421-460).
     Chain c = r * n_eps + e shares region r's series."""
-    reg = make_regions(n_regions)
-    u_hist = make_npi_history(n_regions, T_hist)
-    obs = simulate_observations(reg, u_hist)
+    reg = make_regions(n_regions, region_offset=region_offset)
+    u_hist = make_npi_history(n_regions, T_hist, seed=1 + region_offset)
+    obs = simulate_observations(reg, u_hist, seed=2 + region_offset)
     T = T_hist + horizon
     x = np.concatenate([obs["x"], np.full((horizon, n_regions), np.nan)], axis=0)
     u = np.concatenate([u_hist, np.full((horizon, NUM_NPI, n_regions), np.nan)], axis=0)
