@@ -72,7 +72,8 @@ def cpu_baseline(w, args):
     """The CPU oracle (C restatement of Tools/*.m, MATLAB unavailable) timed on this host's cores over a
     bounded sample of the same workload: every k-th chain, all days, all outputs."""
     from tests import helpers as H
-    cores = os.cpu_count() or 1
+    # a one-GPU box grants this job a 16-CPU share; never spawn more OpenMP threads than that
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     n = args.cpu_sample_chains
     if n <= 0:
         # ~20 k steps/s/core for the 6-state filter+smoother, ~80 k for the 3-state one: aim at ~15 s
