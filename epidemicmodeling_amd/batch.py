@@ -139,3 +139,57 @@ def gather_to_root(t: torch.Tensor, group=None, dst: int = 0):
     bufs = [torch.empty_like(t) for _ in range(world)] if dist.get_rank(group) == dst else None
     dist.gather(t, bufs, dst=dst, group=group)
     return bufs
+
+
+# ---------------------------------------------------------------------------
+# forward simulators (Tools/SIalpha_Controlled.m, Tools/SEIRP.m, Tools/NPICost.m) on the device
+# ---------------------------------------------------------------------------
+SIM_FIELDS = {"s0": 0, "i0": 1, "alpha0": 2, "alpha_min": 3, "alpha_max": 4, "gamma": 5, "b": 6, "beta": 7,
+              "s_noise_std": 8, "i_noise_std": 9, "alpha_noise_std": 10, "dt": 11}
+SIM_A, SIM_U_MAX, SIM_W, SIM_PRM_COUNT = 12, 24, 36, 48
+
+
+def sialpha_sim(u, sp, z=None, u_series=None, with_cost=False, store=True, device="cuda:0"):
+    """Batched SIalpha_Controlled (+ fused NPICost).  u [K, n_npi, Su], sp [48, B] (SIM_* rows), z [K, 3, B]
+    standard-normal draws or None.  Returns dict of torch tensors s,i,alpha [K,B] (+ J0,J1 [B])."""
+    dev = torch.device(device)
+    t = lambda a, dt=torch.float64: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev) \
+        if not isinstance(a, torch.Tensor) else a
+    u, sp, z = t(u), t(sp), t(z)
+    us = t(u_series, torch.int32)
+    K, n_npi, Su = u.shape
+    B = sp.shape[1]
+    d = _lib.SimDesc()
+    d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, B, K, Su, n_npi
+    d.noise, d.with_cost, d.reserved = int(z is not None), int(with_cost), 0
+    out = {}
+    if store:
+        for n in ("s", "i", "alpha"):
+            out[n] = torch.empty((K, B), dtype=torch.float64, device=dev)
+    if with_cost:
+        out["J0"] = torch.empty((B,), dtype=torch.float64, device=dev)
+        out["J1"] = torch.empty((B,), dtype=torch.float64, device=dev)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_sialpha_sim_device(C.byref(d), _ptr(us), _ptr(u), _ptr(sp), _ptr(z), _ptr(out.get("s")),
+                                           _ptr(out.get("i")), _ptr(out.get("alpha")), _ptr(out.get("J0")),
+                                           _ptr(out.get("J1")), C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return out
+
+
+def seirp_sim(par, init, dt, K, sat=None, integrator="euler", device="cuda:0"):
+    """Batched SEIRP / SEIRPSaturatedResource.  par [K or 1, 7, B], init [5, B], sat [6, B] or None.
+    Returns torch tensor [K, 5, B] (s,e,i,r,p rows; row 0 is the initial condition, SEIRP.m:20-24)."""
+    dev = torch.device(device)
+    t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev)
+    par, init, sat = t(par), t(init), t(sat)
+    B = init.shape[1]
+    out = torch.empty((K, 5, B), dtype=torch.float64, device=dev)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_seirp_sim_device(B, K, par.shape[0], float(dt), int(sat is not None),
+                                         {"euler": 0, "rk4": 1}[integrator], _ptr(par), _ptr(init), _ptr(sat),
+                                         _ptr(out), C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return out

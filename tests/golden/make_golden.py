@@ -1,0 +1,79 @@
+"""Generates tests/golden/*.npz: seeded inputs + expected outputs of the EKF/EKS hot path.
+
+The reference (MATLAB) cannot run in the build image and ships no golden vectors of its own
+(SURVEY.md 4 / 8c), so the vectors are produced by the repo's two independent restatements of the
+.m sources: outputs come from oracle/ekf_oracle.c, and generation FAILS unless oracle/ekf_numpy.py
+(LAPACK pinv / LU) agrees with it on every chain (forward quantities <= 1e-9 relative, identical pinv
+truncation ranks).  Only data is stored: inputs and expected outputs.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from epidemicmodeling_amd import synth  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FWD = ["u_opt", "S_MINUS", "S_PLUS", "P_MINUS", "P_PLUS", "K_GAIN", "innovations", "rho"]
+
+CASES = {
+    "sia3_cfg3": lambda: synth.make_cfg3(4, 90),
+    "sia6_cfg4": lambda: synth.make_cfg4(2, 3, 60, 25),
+    "sia6_row3_adaptiveR": lambda: synth.make_row3(2, 4, 30, 50),
+    "newcase6_row4": lambda: synth.make_row4(3, 90, 30),
+    "newcase6_codegen_row4": lambda: synth.make_row4(2, 90, 30, codegen=True),
+    "sia3_backward": lambda: synth.as_backward(synth.make_cfg3(3, 80)),
+    "sia6_backward": lambda: synth.as_backward(synth.make_cfg4(2, 2, 40, 0)),
+}
+
+
+def pack_inputs(w):
+    d = {"model": np.array(w.model), "T": w.T, "n_npi": w.n_npi, "L": w.L, "order": w.order,
+         "obs_type": np.array(w.obs_type), "x": w.x, "u": w.u, "prm": w.prm, "s_init": w.s_init,
+         "Ps_init": w.Ps_init, "s_final": w.s_final, "Ps_final": w.Ps_final, "Q": w.Q}
+    for k in ("R_series", "R_scalar", "x_series", "u_series"):
+        v = getattr(w, k)
+        if v is not None:
+            d[k] = v
+    return {"in_" + k: v for k, v in d.items()}
+
+
+def main():
+    for name, mk in CASES.items():
+        w = mk()
+        ob = H.oracle_batch(w)
+        names = [n for n in H.OUT_NAMES if not (w.model.startswith("NewCase") and n == "u_opt_smooth")]
+        worst_smooth = 0.0
+        for c in range(w.B):
+            nd = H.numpy_chain(w, c)
+            for n in FWD:
+                e = H.rel_err(H.batch_chain(ob, n, c, w.m), nd[n])
+                assert e <= 1e-9, (name, c, n, e)
+            if "pinv_rank" in nd:
+                assert np.array_equal(nd["pinv_rank"], ob["pinv_rank"][:, c]), (name, c, "pinv rank")
+            # smoothed states: conditioned by pinv of matrices with cond up to 1e60 whose kept singular
+            # values sit just above MATLAB's cut-off -- two SVD implementations agree on the truncation
+            # rank but not on those values' trailing digits, so the gate is loose and the measured
+            # disagreement is stored with the fixture (meta_smooth_disagreement)
+            e = H.rowwise_abs_rel_err(H.batch_chain(ob, "S_SMOOTH", c, w.m)[:3], nd["S_SMOOTH"][:3])
+            worst_smooth = max(worst_smooth, e)
+            assert e <= 5e-2, (name, c, "S_SMOOTH", e)
+        out = pack_inputs(w)
+        out["meta_smooth_disagreement"] = worst_smooth
+        for n in names:
+            out["out_" + n] = ob[n]
+        out["out_pinv_rank"] = ob["pinv_rank"]
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: B={w.B} T={w.T} -> {os.path.getsize(path) / 1024:.0f} KiB; "
+              f"C-vs-NumPy smoothed-state disagreement {worst_smooth:.1e}")
+
+
+if __name__ == "__main__":
+    main()

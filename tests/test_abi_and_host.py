@@ -1,0 +1,179 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/epiekf.h declares, descriptor
+validation mirrors the reference's error() behaviour (no compute calls without a GPU), and the host-side
+mirror of the Tools/ interface resolves MATLAB's argument quirks correctly."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from epidemicmodeling_amd import layout as L
+from epidemicmodeling_amd import synth
+from tests import helpers as H
+
+
+def _declared_functions():
+    src = open(os.path.join(H.ROOT, "include", "epiekf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(epi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from epidemicmodeling_amd import _lib
+    names = _declared_functions()
+    assert set(_lib.ABI_SYMBOLS) == set(names), (names, _lib.ABI_SYMBOLS)
+    for n in names:
+        assert hasattr(hip_lib, n), f"libepiekf.so does not export {n}"
+    assert hip_lib.epi_abi_version() == 1
+
+
+def test_layout_header_matches_python_mirror():
+    src = open(os.path.join(H.ROOT, "include", "epiekf_layout.h")).read()
+    vals = dict((k, int(v)) for k, v in re.findall(r"(EPI_PRM_[A-Z_]+)\s*=\s*(\d+)", src))
+    for k, v in vals.items():
+        assert getattr(L, k.replace("EPI_PRM_", "PRM_")) == v
+    hdr = open(os.path.join(H.ROOT, "include", "epiekf.h")).read()
+    for name, bit in re.findall(r"EPI_OUT_([A-Z_]+)\s*=\s*1 << (\d+)", hdr):
+        key = {"U_OPT": "u_opt", "U_OPT_SMOOTH": "u_opt_smooth", "INNOVATIONS": "innovations", "RHO": "rho",
+               "K_GAIN": "K_GAIN"}.get(name, name)
+        assert L.OUT_BITS[key] == 1 << int(bit)
+
+
+def test_model_dims(hip_lib):
+    assert [hip_lib.epi_model_dim(i) for i in range(7)] == [3, 6, 3, 6, 6, 6, -1]
+
+
+def _desc(**kw):
+    from epidemicmodeling_amd import _lib
+    base = dict(model="SIAlphaModelEKF", B=4, T=10, Sx=4, Su=4, n_npi=12, L_=21, order=1, obs_type="NEWCASES",
+                r_mode=1, out_mask=L.OUT_ALL)
+    base.update(kw)
+    return _lib.make_desc(**base)
+
+
+@pytest.mark.parametrize("kw,code,msg", [
+    (dict(order=3), -1, "Undefined order"),
+    (dict(order=0), -1, "Undefined order"),
+    (dict(obs_type="DEATHS"), -4, "unknown observation type"),
+    (dict(r_mode=2), -3, "Observation noise covariance noise mismatch"),
+    (dict(model="NewCaseEKFEstimatorWithOptimalNPI", r_mode=1), -3, "Observation noise covariance noise mismatch"),
+    (dict(n_npi=13), -5, None), (dict(B=0), -5, None), (dict(L_=0), -5, None), (dict(L_=200), -8, None),
+])
+def test_validate_mirrors_reference_errors(hip_lib, kw, code, msg):
+    d = _desc(**kw)
+    err = C.create_string_buffer(256)
+    assert hip_lib.epi_ekf_validate(C.byref(d), err) == code
+    if msg:
+        assert err.value.decode() == msg
+
+
+def test_validate_accepts_order_two_and_codegen_ignores_obs_type(hip_lib):
+    err = C.create_string_buffer(256)
+    assert hip_lib.epi_ekf_validate(C.byref(_desc(order=2)), err) == 0
+    d = _desc(model="NewCaseEKFEstimatorWithOptimalNPI_codegen", obs_type="whatever", r_mode=0)
+    assert hip_lib.epi_ekf_validate(C.byref(d), err) == 0     # MatlabCodeGenerator/NlinObsUpdate.m has no obs_type
+
+
+def test_workspace_covers_unselected_forward_quantities(hip_lib):
+    full = hip_lib.epi_ekf_workspace_bytes(C.byref(_desc(model="SIAlphaModelEKFOptControlled")))
+    assert full == 0
+    red = _desc(model="SIAlphaModelEKFOptControlled", out_mask=L.OUT_BITS["u_opt_smooth"] | L.OUT_BITS["S_SMOOTH"])
+    need = 4 * 10 * 8 * (6 + 6 + 36 + 36)
+    got = hip_lib.epi_ekf_workspace_bytes(C.byref(red))
+    assert need <= got <= need + 4 * 256
+
+
+def test_run_device_argument_checks_without_gpu(hip_lib):
+    """NULL arrays / identity-map size errors are caught on the host before any HIP call."""
+    from epidemicmodeling_amd import _lib
+    err = C.create_string_buffer(256)
+    ins, outs = _lib.Inputs(), _lib.Outputs()
+    rc = hip_lib.epi_ekf_run_device(C.byref(_desc()), C.byref(ins), C.byref(outs), None, 0, None, err)
+    assert rc == -5 and b"NULL input array" in err.value
+
+
+# ------------------------------------------------------------------ host mirror of Tools/
+def test_resolve_w_implicit_expansion_quirk():
+    from epidemicmodeling_amd.tools import resolve_w
+    w = np.arange(1.0, 13.0)
+    assert np.array_equal(resolve_w(w.reshape(12, 1), 12), w)               # column: w(kk)
+    assert np.array_equal(resolve_w(w.reshape(1, 12), 12), np.full(12, 1.0))  # row: w(1) for every NPI
+    wd = np.arange(24.0).reshape(12, 2)
+    assert np.array_equal(resolve_w(wd, 12), wd[:, 0])                      # 12 x D: first day's column
+    assert np.array_equal(resolve_w(np.nan, 12), np.full(12, np.nan), equal_nan=True)
+    from oracle.ekf_numpy import resolve_w as resolve_w_oracle             # the checker agrees
+    for cand in (w.reshape(12, 1), w.reshape(1, 12), wd, 3.0):
+        assert np.array_equal(resolve_w(cand, 12), resolve_w_oracle(cand, 12))
+
+
+def _params3():
+    return dict(dt=1.0, a=np.zeros(12), b=0.0, u_max=synth.IP_MAXES, alpha_min=1e-8, alpha_max=100.0, gamma=1 / 7,
+                beta=synth.MODEL_BETA, obs_type="NEWCASES", s_min=1e-6, i_min=1e-6)
+
+
+def _call3(**over):
+    from epidemicmodeling_amd import tools
+    T = 20
+    args = dict(u=np.zeros((12, T)), x=np.full((1, T), 1e-5), params=_params3(), s_init=[0.99, 0.01, 1.1],
+                Ps_init=np.eye(3) * 1e-4, s_final=np.full(3, np.nan), Ps_final=np.full((3, 3), np.nan),
+                w_bar=np.zeros(3), v_bar=0, Q_w=np.eye(3) * 1e-6, R_v=1e-10, beta=1.0, gamma=0.995,
+                inv_monitor_len=21, order=1)
+    args.update(over)
+    return tools.SIAlphaModelEKF(**args)
+
+
+def test_tools_error_behaviour_matches_reference(hip_lib):
+    from epidemicmodeling_amd.tools import EpiError
+    with pytest.raises(EpiError, match="Undefined order"):
+        _call3(order=3)
+    with pytest.raises(EpiError, match="Observation noise covariance noise mismatch"):
+        _call3(R_v=np.ones(7))
+    with pytest.raises(EpiError, match="Process noise covariance noise mismatch"):
+        _call3(Q_w=np.ones((2, 3)))
+    p = _params3(); p["obs_type"] = "DEATHS"
+    with pytest.raises(EpiError, match="unknown observation type"):
+        _call3(params=p)
+    p = _params3(); del p["s_min"]
+    with pytest.raises(KeyError, match="non-existent field"):
+        _call3(params=p)
+
+
+def test_tools_needs_the_hip_library_no_cpu_fallback(hip_lib):
+    """Without a GPU the product path fails loudly with a HIP error -- it never computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from epidemicmodeling_amd.tools import EpiError
+    with pytest.raises(EpiError) as ei:
+        _call3()
+    assert ei.value.status == -7
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(H.ROOT, "epidemicmodeling_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in re.sub(r'""".*?"""|#.*|//.*', "", txt, flags=re.S), f
+
+
+def test_synth_is_deterministic_and_shapes():
+    a, b = synth.make_cfg4(5, 4, 30, 10), synth.make_cfg4(5, 4, 30, 10)
+    for k in ("x", "u", "prm", "Q", "Ps_final"):
+        assert np.array_equal(getattr(a, k), getattr(b, k), equal_nan=True)
+    assert a.B == 20 and a.T == 40 and a.Sx == 5 and np.isnan(a.x[30:]).all() and np.isnan(a.u[30:]).all()
+    eps = synth.epsilon_grid(250)
+    assert eps.shape == (250,) and eps[0] == 1e-12 and eps[-1] == 1 - np.finfo(float).eps
+    sub = a.select([3, 7, 19])
+    assert sub.B == 3 and sub.Sx == 3 and list(sub.x_series) == [0, 1, 2]
+
+
+def test_shard_chains_partitions_exactly():
+    from epidemicmodeling_amd.batch import shard_chains
+    for B in (1, 7, 64, 75000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_chains(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
