@@ -108,7 +108,7 @@ def _run(model, u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, 
         Qm = float(Q.reshape(-1)[0]) * np.eye(m)          # B*Q*B' with B = eye(m)
     elif Q.ndim == 2 and Q.shape == (m, m):
         Qm = Q
-    elif (Q.ndim == 3 and Q.shape[:2] == (m, m) and Q.shape[2] == T) or (Q.ndim <= 2 and Q.size == T and min(Q.shape) == 1):
+    elif (Q.ndim == 3 and Q.shape[:2] == (m, m) and Q.shape[2] == T) or ((Q.ndim == 1 or (Q.ndim == 2 and min(Q.shape) == 1)) and Q.size == T):
         raise EpiError(-8, "time-varying Q_w is valid in the reference but not supported by this engine")
     else:
         raise EpiError(-2, "Process noise covariance noise mismatch")
@@ -117,7 +117,7 @@ def _run(model, u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, 
     generic = not model.startswith("NewCase")
     if R.size == 1:
         r_mode, R_scalar, R_series = 0, np.array([float(R.reshape(-1)[0])]), None
-    elif generic and R.ndim <= 2 and min(R.shape) == 1 and R.size == T:
+    elif generic and (R.ndim == 1 or (R.ndim == 2 and min(R.shape) == 1)) and R.size == T:   # isvector && length == T
         r_mode, R_scalar, R_series = 1, None, np.ascontiguousarray(R.reshape(T, 1))
     else:
         raise EpiError(-3, "Observation noise covariance noise mismatch")

@@ -89,9 +89,20 @@ def make_params(p, n_npi, w_eff):
     """p: any object with the reference's params fields (dict or attribute style)."""
     g = (lambda k: p[k]) if isinstance(p, dict) else (lambda k: getattr(p, k))
     cp = _Params()
+    optional = {"sigma": 1.0, "epsilon": float("nan"), "s_min": 0.0, "i_min": 0.0}   # not read by every model
     for k in ("dt", "beta", "gamma", "sigma", "b", "epsilon", "s_min", "i_min", "alpha_min", "alpha_max"):
-        setattr(cp, k, float(g(k)))
-    for name, src in (("a", g("a")), ("u_min", g("u_min")), ("u_max", g("u_max")), ("w_eff", w_eff)):
+        try:
+            v = g(k)
+        except (KeyError, AttributeError):
+            if k not in optional:
+                raise
+            v = optional[k]
+        setattr(cp, k, float(v))
+    try:
+        u_min = g("u_min")
+    except (KeyError, AttributeError):
+        u_min = np.zeros(MAX_NPI)
+    for name, src in (("a", g("a")), ("u_min", u_min), ("u_max", g("u_max")), ("w_eff", w_eff)):
         v = np.zeros(MAX_NPI)
         sv = np.asarray(src, dtype=np.float64).reshape(-1)
         v[:sv.size] = sv
