@@ -120,8 +120,9 @@ def main():
         if events is None:
             runner.run()
         else:
-            e0, e1, e2 = events
-            e0.record(); runner.run(phase=1); e1.record(); runner.run(phase=2); e2.record()
+            e0, e1, e2, e3 = events
+            e0.record(); runner.run(phase=1); e1.record(); runner.run(phase=3); e2.record()
+            runner.run(phase=4); e3.record()
         if world > 1:
             # end-of-sweep result gather (per-chain smoothed state at the last observed day) to rank 0
             batch.gather_to_root(runner.out["S_SMOOTH"][t_hist_idx].contiguous())
@@ -129,7 +130,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -146,18 +147,22 @@ def main():
         elapsed = float(tt.item())
 
     ms_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    ms_bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    ms_pinv = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    ms_bwd = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
     if rank == 0:
         total_steps = steps_per_pass * world * args.steps
         value = total_steps / elapsed
         full = args.outputs == "all"
-        b_fwd = BYTES_FWD[m] if full else 112
-        b_bwd = BYTES_BWD[m] if full else 8 * (m + 12)
-        dom_is_bwd = ms_bwd >= ms_fwd
-        dom_ms = ms_bwd if dom_is_bwd else ms_fwd
-        dom_bytes = (b_bwd if dom_is_bwd else b_fwd) * steps_per_pass
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        step_gbs = (b_fwd + b_bwd) * steps_per_pass / ((ms_fwd + ms_bwd) * 1e-3) / 1e9
+        # algorithmic bytes per region-day step, split by kernel: eks_pinv produces no reference
+        # output of its own -- its algorithmic bytes are the P_MINUS it must read (m*m doubles)
+        alg = {"ekf_fwd": BYTES_FWD[m] if full else 112, "eks_pinv": 8 * m * m,
+               "eks_bwd": BYTES_BWD[m] if full else 8 * (m + 12)}
+        ms = {"ekf_fwd": ms_fwd, "eks_pinv": ms_pinv, "eks_bwd": ms_bwd}
+        dom = max(ms, key=ms.get)
+        dom_bytes = alg[dom] * steps_per_pass
+        achieved = dom_bytes / (ms[dom] * 1e-3) / 1e9
+        step_bytes = (BYTES_PER_STEP_FULL[m] if full else 112 + 8 * (m + 12)) * steps_per_pass
+        step_gbs = step_bytes / (sum(ms.values()) * 1e-3) / 1e9
         res = {
             "metric": "region-day EKF steps/sec (300 regions x 400 days x 250 costs)",
             "value": value, "unit": "region-day EKF steps/s", "n_gpus": world, "steps": args.steps,
@@ -168,13 +173,12 @@ def main():
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
                        "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "eks_bwd" if dom_is_bwd else "ekf_fwd",
-                         "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": dom_bytes},
-            "kernels": {"ekf_fwd_ms": ms_fwd, "eks_bwd_ms": ms_bwd,
-                        "ekf_fwd_GBs": b_fwd * steps_per_pass / (ms_fwd * 1e-3) / 1e9,
-                        "eks_bwd_GBs": b_bwd * steps_per_pass / (ms_bwd * 1e-3) / 1e9,
-                        "whole_step_GBs": step_gbs, "whole_step_frac_of_hbm_peak": step_gbs / HBM_PEAK_GBS},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                         "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes},
+            "kernels": {**{k + "_ms": v for k, v in ms.items()},
+                        **{k + "_GBs": alg[k] * steps_per_pass / (ms[k] * 1e-3) / 1e9 for k in ms},
+                        "whole_step_algorithmic_bytes": step_bytes, "whole_step_GBs": step_gbs,
+                        "whole_step_frac_of_hbm_peak": step_gbs / HBM_PEAK_GBS},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, args)

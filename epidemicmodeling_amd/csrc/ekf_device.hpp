@@ -6,11 +6,14 @@
 // cross-lane traffic, and every global access is one coalesced 512-byte row
 // of a time-major / chain-minor array.
 //
-// Arithmetic contract: IEEE fp64, one rounding per written operation (the
-// library is built with -ffp-contract=off), evaluated in the order the
-// reference's MATLAB expressions are written (left to right; matrix products
-// as sum_k A(i,k)*B(k,j), k ascending).  Citations: Tools/*.m of the
-// reference, file:line.
+// Arithmetic contract: IEEE fp64, built with -ffp-contract=off so the compiler
+// never fuses on its own.  Scalar / element-wise MATLAB expressions are
+// evaluated as written, one rounding per * + - /.  BLAS-class operations
+// (matrix-matrix, matrix-vector, dot products -- what MATLAB hands to its BLAS)
+// accumulate with an explicit fma():  acc = a0*b0; acc = fma(a_k, b_k, acc),
+// k ascending.  The Jacobi eigen-solver behind pinv uses fma() in its rotations.
+// The CPU oracle uses the same fma() in the same places => bit-identical results.
+// Citations: Tools/*.m of the reference, file:line.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -75,7 +78,7 @@ EPI_DEV void mat_mul(const double (&A)[M * M], const double (&B)[M * M], double 
         for (int i = 0; i < M; i++) {
             double acc = A[IXM(i, 0)] * B[IXM(0, j)];
 #pragma unroll
-            for (int k = 1; k < M; k++) acc = acc + A[IXM(i, k)] * B[IXM(k, j)];
+            for (int k = 1; k < M; k++) acc = fma(A[IXM(i, k)], B[IXM(k, j)], acc);
             C[IXM(i, j)] = acc;
         }
 }
@@ -88,7 +91,7 @@ EPI_DEV void mat_mul_bt(const double (&A)[M * M], const double (&B)[M * M], doub
         for (int i = 0; i < M; i++) {
             double acc = A[IXM(i, 0)] * B[IXM(j, 0)];
 #pragma unroll
-            for (int k = 1; k < M; k++) acc = acc + A[IXM(i, k)] * B[IXM(j, k)];
+            for (int k = 1; k < M; k++) acc = fma(A[IXM(i, k)], B[IXM(j, k)], acc);
             C[IXM(i, j)] = acc;
         }
 }
@@ -144,7 +147,7 @@ EPI_DEV void nlin_state_update(const ChainPrm &p, const ModelFlags &mf, double (
     // params.gamma * params.a' * (params.u_max - u): row vector (gamma*a') times column
     double dot = (p.gamma * p.a[0]) * (p.u_max[0] - u[0]);
 #pragma unroll
-    for (int k = 1; k < kNpi; k++) dot = dot + (p.gamma * p.a[k]) * (p.u_max[k] - u[k]);
+    for (int k = 1; k < kNpi; k++) dot = fma(p.gamma * p.a[k], p.u_max[k] - u[k], dot);
     const double asi = s[2] * s[0] * s[1];
     const double f3 = -p.gamma * s[2] + p.gamma * p.b + dot;
     if (!FLIP) {
@@ -283,8 +286,8 @@ template <int M>
 EPI_DEV void jacobi_rot(double &x, double &y, double s, double tau)
 {
     double g = x, h = y;
-    x = g - s * (h + g * tau);
-    y = h + s * (g - h * tau);
+    x = fma(-s, fma(g, tau, h), g);
+    y = fma(s, fma(-h, tau, g), h);
 }
 
 // a: symmetric, only the upper triangle (i <= j) is read/updated.  Returns true if the sweep cap was hit.
@@ -321,13 +324,17 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
                     if ((fabs(h) + g) == fabs(h)) {
                         t = apq / h;
                     } else {
-                        double theta = 0.5 * h / apq;
-                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
-                        if (theta < 0.0) t = -t;
+                        // t = sgn(theta)/(|theta| + sqrt(theta^2+1)), theta = h/(2 apq), times |2 apq| through
+                        const double two_apq = 2.0 * apq;
+                        t = two_apq / (fabs(h) + sqrt(fma(h, h, two_apq * two_apq)));
+                        if (h < 0.0) t = -t;
                     }
-                    const double c = 1.0 / sqrt(1.0 + t * t);
+                    // c = 1/r, tau = s/(1+c) = t/(1+r), r = sqrt(1+t^2): one division serves both
+                    const double r = sqrt(fma(t, t, 1.0));
+                    const double ir = 1.0 / fma(r, r, r);
+                    const double c = (1.0 + r) * ir;
                     const double s = t * c;
-                    const double tau = s / (1.0 + c);
+                    const double tau = (t * r) * ir;
                     h = t * apq;
                     z[p] = z[p] - h;
                     z[q] = z[q] + h;
@@ -385,7 +392,7 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped)
             for (int c = 0; c < M; c++)
 #pragma unroll
                 for (int r = 0; r < M; r++)
-                    X[IXM(r, c)] = X[IXM(r, c)] + (v[IXM(r, i)] * inv) * (sg * v[IXM(c, i)]);
+                    X[IXM(r, c)] = fma(v[IXM(r, i)] * inv, sg * v[IXM(c, i)], X[IXM(r, c)]);
         }
     }
 #pragma unroll

@@ -37,6 +37,11 @@ struct KArgs {
     // optional outputs (NULL = not stored)
     double *u_opt, *u_opt_smooth, *S_SMOOTH, *P_SMOOTH, *K_GAIN, *innovations, *rho;
     int32_t *pinv_rank, *status;
+    // smoother intermediates (workspace): X = pinv(P_MINUS(:,:,k+1)) stored at the position of step k+1,
+    // rankbuf = kept rank | sweep-cap flag << 8 (or -1 where the non-finite guard of :211 fired)
+    double *X;
+    int32_t *rankbuf;
+    int pinv_pos0;
 };
 
 // position in the caller's time axis of filter step k (flipped wrappers run the
@@ -143,19 +148,19 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
             for (int i = 0; i < M; i++) {
                 double acc = Pk_minus[IXM(i, 0)] * C[0];
 #pragma unroll
-                for (int j = 1; j < M; j++) acc = acc + Pk_minus[IXM(i, j)] * C[j];
+                for (int j = 1; j < M; j++) acc = fma(Pk_minus[IXM(i, j)], C[j], acc);
                 PCt[i] = acc;
             }
 #pragma unroll
             for (int j = 0; j < M; j++) {
                 double acc = C[0] * Pk_minus[IXM(0, j)];
 #pragma unroll
-                for (int i = 1; i < M; i++) acc = acc + C[i] * Pk_minus[IXM(i, j)];
+                for (int i = 1; i < M; i++) acc = fma(C[i], Pk_minus[IXM(i, j)], acc);
                 CP[j] = acc;
             }
             double CPCt = CP[0] * C[0];
 #pragma unroll
-            for (int j = 1; j < M; j++) CPCt = CPCt + CP[j] * C[j];
+            for (int j = 1; j < M; j++) CPCt = fma(CP[j], C[j], CPCt);
             const double den = CPCt + gamma * Rk;          // :124 (D = 1, Hessian terms 0)
 #pragma unroll
             for (int i = 0; i < M; i++) K[i] = PCt[i] / den;
@@ -247,6 +252,49 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// smoother gain, part 1: X = pinv(P_MINUS(:,:,k+1)) for every (chain, step) pair
+// ---------------------------------------------------------------------------
+// GenericEKF.m:209-215.  pinv of P(k+1|k) depends only on forward quantities, not on the backward
+// recursion, so it is hoisted out of the sequential smoother loop: one lane per (chain, step) pair,
+// (T-1)*B independent items.  This is where ~80 % of the path's flops are (cyclic Jacobi on a 6 x 6),
+// and as a flat grid it load-balances over all 1024 SIMDs instead of B/64 long-lived waves.
+template <int M>
+__global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
+{
+    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)(a.T - 1) * a.B;
+    if (item >= total) return;
+    const int B = a.B;
+    // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
+    const int t1 = a.pinv_pos0 + (int)(item / B);
+    const int c = (int)(item % B);
+    double P[M * M];
+    // P_MINUS is stored symmetrised (:161): read the upper triangle only and mirror it
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i <= j; i++) {
+            const double v = a.P_MINUS[((size_t)t1 * (M * M) + IXM(i, j)) * B + c];
+            P[IXM(i, j)] = v;
+            P[IXM(j, i)] = v;
+        }
+    bool bad = false;                                      // :211
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i <= j; i++) bad = bad || is_nonfinite(P[IXM(i, j)]);
+    if (bad) {
+        a.rankbuf[(size_t)t1 * B + c] = -1;
+        return;
+    }
+    double X[M * M];
+    bool capped;
+    const int rank = sym_pinv<M>(P, X, &capped);           // :215
+    store_mat<M>(a.X, t1, B, c, X);
+    a.rankbuf[(size_t)t1 * B + c] = rank | (capped ? 0x100 : 0);
+}
+
+// ---------------------------------------------------------------------------
 // backward pass (fixed-interval smoother)
 // ---------------------------------------------------------------------------
 template <int M, int FLIP, int GENERIC>
@@ -321,19 +369,18 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
             state_jacobians<M, FLIP>(p, u_in, Sp, A);          // :206
             mat_mul_bt<M>(Pp, A, PAt);                         // P_PLUS * A'
             if (GENERIC) {
-                bool bad = false;                              // :211
-#pragma unroll
-                for (int e = 0; e < M * M; e++) bad = bad || is_nonfinite(Pm1[e]);
-                if (bad) {
+                // pinv(P_MINUS(:,:,k+1)) was computed by eks_pinv (one lane per (chain, step) pair)
+                const int rk = a.rankbuf[(size_t)t1 * B + c];
+                if (rk < 0) {                                  // non-finite P_MINUS guard :211-213
 #pragma unroll
                     for (int e = 0; e < M * M; e++) J[e] = 0.0;
                     st_guard = 1;
                 } else {
                     double X[M * M];
-                    bool capped;
-                    rank = sym_pinv<M>(Pm1, X, &capped);       // :215
-                    mat_mul<M>(PAt, X, J);
-                    st_cap |= capped ? 1 : 0;
+                    load_mat<M>(a.X, t1, B, c, X);
+                    mat_mul<M>(PAt, X, J);                     // :215
+                    rank = rk & 0xff;
+                    st_cap |= (rk >> 8) & 1;
                     min_rank = rank < min_rank ? rank : min_rank;
                 }
             } else {
@@ -351,7 +398,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
             for (int i = 0; i < M; i++) {
                 double acc = J[IXM(i, 0)] * dv[0];
 #pragma unroll
-                for (int j = 1; j < M; j++) acc = acc + J[IXM(i, j)] * dv[j];
+                for (int j = 1; j < M; j++) acc = fma(J[IXM(i, j)], dv[j], acc);
                 Sn[i] = Sp[i] + acc;                           // :218
             }
         }
@@ -408,7 +455,7 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
         for (int k = 0; k < kNpi; k++) uk[k] = (k < d.n_npi) ? u[((size_t)t * d.n_npi + k) * d.Su + su] : 0.0;
         double dot = ga[0] * (um[0] - uk[0]);
 #pragma unroll
-        for (int k = 1; k < kNpi; k++) dot = dot + ga[k] * (um[k] - uk[k]);
+        for (int k = 1; k < kNpi; k++) dot = fma(ga[k], um[k] - uk[k], dot);
         double z1 = 0.0, z2 = 0.0, z3 = 0.0;
         if (d.noise) {
             z1 = z[((size_t)t * 3 + 0) * B + c]; z2 = z[((size_t)t * 3 + 1) * B + c]; z3 = z[((size_t)t * 3 + 2) * B + c];
@@ -514,7 +561,7 @@ static int hip_fail(char *err, hipError_t e, const char *what)
     return EPI_ERR_HIP;
 }
 
-struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, total; };
+struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, total; };
 static WsLayout ws_layout(const epi_batch_desc *d)
 {
     const int m = MODEL_TABLE[d->model].m;
@@ -526,27 +573,37 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.s_plus = take(!(d->out_mask & EPI_OUT_S_PLUS), nS);
     w.p_minus = take(!(d->out_mask & EPI_OUT_P_MINUS), nP);
     w.p_plus = take(!(d->out_mask & EPI_OUT_P_PLUS), nP);
+    // smoother intermediates of the generic models: X = pinv(P_MINUS) and its rank word per (step, chain)
+    const bool generic = MODEL_TABLE[d->model].generic;
+    w.x = take(generic, nP);
+    w.rank = take(generic, (size_t)d->T * d->B * sizeof(int32_t));
     w.total = off;
     return w;
 }
 
+// phase: 0 = everything; 1 = forward kernel; 2 = smoother (pinv + backward); 3 = pinv kernel; 4 = backward kernel
 template <int M, int FLIP, int GENERIC>
-static hipError_t launch_pair(const KArgs &ka, bool forward, bool smooth, hipStream_t st)
+static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, hipStream_t st)
 {
     const int blocks = (ka.B + kWave - 1) / kWave;
     const size_t shmem = (size_t)3 * ka.L * kWave * sizeof(double);
     hipError_t e = hipSuccess;
-    if (forward) {
+    if (phase == 0 || phase == 1) {
         if (shmem > 64u * 1024u) {   // above the default dynamic-LDS limit
             e = hipFuncSetAttribute((const void *)ekf_fwd<M, FLIP, GENERIC>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (smooth) {
+    if (!smooth) return e;
+    if (GENERIC && ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
+        const size_t items = (size_t)(ka.T - 1) * ka.B;
+        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ka);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (phase == 0 || phase == 2 || phase == 4) {
         hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
         e = hipGetLastError();
     }
@@ -597,7 +654,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
         set_err(err, epi_status_string(EPI_ERR_R_MISMATCH)); return EPI_ERR_R_MISMATCH;
     }
     // three fp64 windows of L samples per lane must fit the CU's 160 KiB LDS
-    if (d->phase < 0 || d->phase > 2) { set_err(err, "phase must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
+    if (d->phase < 0 || d->phase > 4) { set_err(err, "phase must be 0..4"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
 }
@@ -653,6 +710,9 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     ka.innovations = sel(EPI_OUT_INNOVATIONS, out->innovations);
     ka.rho = sel(EPI_OUT_RHO, out->rho);
     ka.pinv_rank = out->pinv_rank; ka.status = out->status;
+    ka.X = mi.generic ? (double *)(ws + wl.x) : nullptr;
+    ka.rankbuf = mi.generic ? (int32_t *)(ws + wl.rank) : nullptr;
+    ka.pinv_pos0 = mi.flipped ? 0 : 1;
     {
         struct { uint32_t bit; const void *p; const char *n; } chk[] = {
             {EPI_OUT_U_OPT, out->u_opt, "u_opt"}, {EPI_OUT_S_MINUS, out->S_MINUS, "S_MINUS"},
@@ -664,18 +724,16 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
             if ((om & q.bit) && !q.p) { char b[128]; snprintf(b, sizeof b, "output %s selected but NULL", q.n); set_err(err, b); return EPI_ERR_BAD_ARG; }
         if (has_uos && (om & EPI_OUT_U_OPT_SMOOTH) && !out->u_opt_smooth) { set_err(err, "output u_opt_smooth selected but NULL"); return EPI_ERR_BAD_ARG; }
     }
-    const bool forward = (d->phase != 2);
-    const bool smooth = (d->phase != 1) &&
-                        ((om & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && (om & EPI_OUT_U_OPT_SMOOTH)) ||
-                         out->pinv_rank || out->status);
+    const bool smooth = (om & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && (om & EPI_OUT_U_OPT_SMOOTH)) ||
+                        out->pinv_rank || out->status;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     switch (d->model) {
-    case EPI_MODEL_SIA3: e = launch_pair<3, 0, 1>(ka, forward, smooth, st); break;
-    case EPI_MODEL_SIA6: e = launch_pair<6, 0, 1>(ka, forward, smooth, st); break;
-    case EPI_MODEL_SIA3_BWD: e = launch_pair<3, 1, 1>(ka, forward, smooth, st); break;
-    case EPI_MODEL_SIA6_BWD: e = launch_pair<6, 1, 1>(ka, forward, smooth, st); break;
-    default: e = launch_pair<6, 0, 0>(ka, forward, smooth, st); break;
+    case EPI_MODEL_SIA3: e = launch_chain<3, 0, 1>(ka, d->phase, smooth, st); break;
+    case EPI_MODEL_SIA6: e = launch_chain<6, 0, 1>(ka, d->phase, smooth, st); break;
+    case EPI_MODEL_SIA3_BWD: e = launch_chain<3, 1, 1>(ka, d->phase, smooth, st); break;
+    case EPI_MODEL_SIA6_BWD: e = launch_chain<6, 1, 1>(ka, d->phase, smooth, st); break;
+    default: e = launch_chain<6, 0, 0>(ka, d->phase, smooth, st); break;
     }
     if (e != hipSuccess) return hip_fail(err, e, "kernel launch");
     return EPI_OK;

@@ -109,9 +109,9 @@ typedef struct epi_batch_desc {
     int32_t r_mode;       /* 0: R_scalar[B] (scalar R_v, adaptive when beta != 1); 1: R_series */
     int32_t q_mode;       /* 0: fixed per-chain m x m Q_w (the only form the reference's callers use) */
     uint32_t out_mask;    /* epi_out bits: which outputs are written */
-    int32_t phase;        /* 0: forward EKF then backward EKS (one reference call); 1: forward kernel only;
-                             2: smoother kernel only (re-uses the forward quantities a phase-1 call left in the
-                             outputs/workspace) -- lets a caller bracket each kernel with its own events */
+    int32_t phase;        /* 0: forward EKF then backward EKS (one reference call).  For per-kernel timing a
+                             caller may enqueue the stages one by one, in order, on the same buffers:
+                             1 = forward kernel; 2 = smoother (3 then 4); 3 = pinv kernel; 4 = backward recursion */
 } epi_batch_desc;
 
 typedef struct epi_inputs {

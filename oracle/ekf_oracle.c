@@ -17,9 +17,16 @@
  * right operand (LU with partial pivoting, LAPACK dgetf2/dgetrs operation
  * order), NaN-ignoring min/max (fmin/fmax), eps, squeeze.
  *
- * Matrix products are evaluated as MATLAB writes them, left to right, each
- * product as  C(i,j) = sum_k A(i,k)*B(k,j)  with k ascending and the first
- * term taken as is (no leading 0 +).
+ * Matrix products are evaluated as MATLAB writes them, left to right.  Every
+ * BLAS-class operation (matrix-matrix, matrix-vector and dot products -- what
+ * MATLAB hands to its BLAS, which uses fused multiply-add on every CPU since
+ * 2013) accumulates with fma():  acc = a(i,0)*b(0,j); acc = fma(a(i,k), b(k,j),
+ * acc) for k = 1..m-1.  Scalar / element-wise MATLAB expressions (the model
+ * maps, Jacobian entries, gains, clamps, the innovation monitor) are NOT fused:
+ * each written * + - / is one IEEE rounding.  fma() is the C99 correctly-rounded
+ * fused multiply-add (build with -mfma so it is one instruction); the HIP
+ * kernels use the same fma() in the same places, so CPU and GPU results are
+ * bit-identical.
  */
 #include "ekf_oracle.h"
 #include "../include/epiekf_layout.h"
@@ -41,7 +48,7 @@ static void mat_mul(int m, const double *A, const double *B, double *C) /* C = A
     for (int j = 0; j < m; j++)
         for (int i = 0; i < m; i++) {
             double acc = A[IX(i, 0, m)] * B[IX(0, j, m)];
-            for (int k = 1; k < m; k++) acc = acc + A[IX(i, k, m)] * B[IX(k, j, m)];
+            for (int k = 1; k < m; k++) acc = fma(A[IX(i, k, m)], B[IX(k, j, m)], acc);
             C[IX(i, j, m)] = acc;
         }
 }
@@ -50,7 +57,7 @@ static void mat_mul_bt(int m, const double *A, const double *B, double *C) /* C 
     for (int j = 0; j < m; j++)
         for (int i = 0; i < m; i++) {
             double acc = A[IX(i, 0, m)] * B[IX(j, 0, m)];
-            for (int k = 1; k < m; k++) acc = acc + A[IX(i, k, m)] * B[IX(j, k, m)];
+            for (int k = 1; k < m; k++) acc = fma(A[IX(i, k, m)], B[IX(j, k, m)], acc);
             C[IX(i, j, m)] = acc;
         }
 }
@@ -110,13 +117,18 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
                     if ((fabs(h) + g) == fabs(h)) {
                         t = apq / h;
                     } else {
-                        double theta = 0.5 * h / apq;
-                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
-                        if (theta < 0.0) t = -t;
+                        /* t = sgn(theta)/(|theta| + sqrt(theta^2+1)), theta = h/(2 apq), multiplied
+                         * through by |2 apq| (the matrix is pre-scaled to max|a| in [1,2): no overflow) */
+                        double two_apq = 2.0 * apq;
+                        t = two_apq / (fabs(h) + sqrt(fma(h, h, two_apq * two_apq)));
+                        if (h < 0.0) t = -t;
                     }
-                    double c = 1.0 / sqrt(1.0 + t * t);
+                    /* c = 1/r, tau = s/(1+c) = t/(1+r) with r = sqrt(1+t^2): one division for both */
+                    double r = sqrt(fma(t, t, 1.0));
+                    double ir = 1.0 / fma(r, r, r);
+                    double c = (1.0 + r) * ir;
                     double s = t * c;
-                    double tau = s / (1.0 + c);
+                    double tau = (t * r) * ir;
                     h = t * apq;
                     z[p] = z[p] - h;
                     z[q] = z[q] + h;
@@ -126,8 +138,8 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
 #define ROT(x, y)                                  \
     do {                                           \
         double g_ = (x), h_ = (y);                 \
-        (x) = g_ - s * (h_ + g_ * tau);            \
-        (y) = h_ + s * (g_ - h_ * tau);            \
+        (x) = fma(-s, fma(g_, tau, h_), g_);       \
+        (y) = fma(s, fma(-h_, tau, g_), h_);       \
     } while (0)
                     for (int j = 0; j < p; j++) ROT(a[IX(j, p, m)], a[IX(j, q, m)]);
                     for (int j = p + 1; j < q; j++) ROT(a[IX(p, j, m)], a[IX(j, q, m)]);
@@ -168,7 +180,7 @@ int orc_sym_pinv(int m, const double *A, double *X)
         double sg = (d[i] < 0.0) ? -1.0 : 1.0;
         for (int c = 0; c < m; c++)
             for (int r = 0; r < m; r++)
-                X[IX(r, c, m)] = X[IX(r, c, m)] + (v[IX(r, i, m)] * inv) * (sg * v[IX(c, i, m)]);
+                X[IX(r, c, m)] = fma(v[IX(r, i, m)] * inv, sg * v[IX(c, i, m)], X[IX(r, c, m)]);
     }
     for (int i = 0; i < m * m; i++) X[i] = ldexp(X[i], -e);
     return rank;
@@ -296,8 +308,8 @@ static void nlin_state_update(const model_ops *mo, const orc_params *p, double *
      * right, i.e. the row vector (gamma*a') times the column (u_max - u) */
     double dot = 0.0;
     for (int kk = 0; kk < p->n_npi; kk++) {
-        double term = (p->gamma * p->a[kk]) * (p->u_max[kk] - u[kk]);
-        dot = (kk == 0) ? term : dot + term;
+        dot = (kk == 0) ? (p->gamma * p->a[kk]) * (p->u_max[kk] - u[kk])
+                        : fma(p->gamma * p->a[kk], p->u_max[kk] - u[kk], dot);
     }
     double asi = s[2] * s[0] * s[1]; /* s_k(3) * s_k(1) * s_k(2) */
     double f3 = -p->gamma * s[2] + p->gamma * p->b + dot;
@@ -475,17 +487,17 @@ static int ekf_core(int model, int T, const double *u_in, const double *x, const
             double PCt[MM];
             for (int i = 0; i < m; i++) {
                 double acc = Pk_minus[IX(i, 0, m)] * C[0];
-                for (int j = 1; j < m; j++) acc = acc + Pk_minus[IX(i, j, m)] * C[j];
+                for (int j = 1; j < m; j++) acc = fma(Pk_minus[IX(i, j, m)], C[j], acc);
                 PCt[i] = acc;
             }
             double CP[MM]; /* Ck*Pk_minus (row vector) */
             for (int j = 0; j < m; j++) {
                 double acc = C[0] * Pk_minus[IX(0, j, m)];
-                for (int i = 1; i < m; i++) acc = acc + C[i] * Pk_minus[IX(i, j, m)];
+                for (int i = 1; i < m; i++) acc = fma(C[i], Pk_minus[IX(i, j, m)], acc);
                 CP[j] = acc;
             }
             double CPCt = CP[0] * C[0];
-            for (int j = 1; j < m; j++) CPCt = CPCt + CP[j] * C[j];
+            for (int j = 1; j < m; j++) CPCt = fma(CP[j], C[j], CPCt);
             double den = CPCt + gamma * Rk;
             for (int i = 0; i < m; i++) K[i] = PCt[i] / den;
             /* eye(m) - Kgain*Ck */
@@ -611,7 +623,7 @@ static int ekf_core(int model, int T, const double *u_in, const double *x, const
             double Sn[MM];
             for (int i = 0; i < m; i++) {
                 double acc = J[IX(i, 0, m)] * dv[0];
-                for (int j = 1; j < m; j++) acc = acc + J[IX(i, j, m)] * dv[j];
+                for (int j = 1; j < m; j++) acc = fma(J[IX(i, j, m)], dv[j], acc);
                 Sn[i] = Sp[i] + acc;
             }
             state_hard_margins(mo, prm, Sn);
@@ -715,8 +727,8 @@ void orc_sialpha_controlled(const double *u, int n_npi, double s0, double i0, do
         double z1 = z ? z[3 * t + 0] : 0.0, z2 = z ? z[3 * t + 1] : 0.0, z3 = z ? z[3 * t + 2] : 0.0;
         double dot = 0.0;
         for (int kk = 0; kk < n_npi; kk++) {
-            double term = (gamma * a[kk]) * (u_max[kk] - u[kk + (size_t)n_npi * t]); /* (gamma*a')*(u_max-u) */
-            dot = (kk == 0) ? term : dot + term;
+            double du = u_max[kk] - u[kk + (size_t)n_npi * t]; /* (gamma*a')*(u_max-u) */
+            dot = (kk == 0) ? (gamma * a[kk]) * du : fma(gamma * a[kk], du, dot);
         }
         double sn = fmax(0.0, fmin(1.0, sp - dt * (ap * sp * ip + z1 * s_noise_std)));                 /* :25 */
         double in = fmax(0.0, fmin(1.0, ip + dt * (ap * sp * ip - beta * ip + z2 * i_noise_std)));     /* :26 */
