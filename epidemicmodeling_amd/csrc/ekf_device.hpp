@@ -33,7 +33,49 @@ constexpr double kEps = 2.220446049250313e-16;  // MATLAB eps
 struct ChainPrm {
     double dt, beta, gamma, sigma, b, epsilon, slo, ilo, alpha_min, alpha_max;
     double a[kNpi], u_min[kNpi], u_max[kNpi], w[kNpi];
+    EPI_DEV double A(int k) const { return a[k]; }
+    EPI_DEV double Umin(int k) const { return u_min[k]; }
+    EPI_DEV double Umax(int k) const { return u_max[k]; }
+    EPI_DEV double W(int k) const { return w[k]; }
 };
+
+// the same constants with the four 12-vectors (a, u_min, u_max, w) left where they are -- in the prm
+// array (re-read through L2 when a step needs them) or in an LDS column -- so that they do not occupy
+// 96 VGPRs for the whole life of the chain
+struct VecGlobal {
+    const double *__restrict__ prm;
+    int B, c;
+    EPI_DEV double A(int k) const { return prm[(size_t)(EPI_PRM_A + k) * B + c]; }
+    EPI_DEV double Umin(int k) const { return prm[(size_t)(EPI_PRM_U_MIN + k) * B + c]; }
+    EPI_DEV double Umax(int k) const { return prm[(size_t)(EPI_PRM_U_MAX + k) * B + c]; }
+    EPI_DEV double W(int k) const { return prm[(size_t)(EPI_PRM_W_EFF + k) * B + c]; }
+};
+struct VecLds {
+    const double *base;   // this lane's column of a [4][12][64] block: a, u_min, u_max, w
+    EPI_DEV double A(int k) const { return base[(0 * kNpi + k) * kWave]; }
+    EPI_DEV double Umin(int k) const { return base[(1 * kNpi + k) * kWave]; }
+    EPI_DEV double Umax(int k) const { return base[(2 * kNpi + k) * kWave]; }
+    EPI_DEV double W(int k) const { return base[(3 * kNpi + k) * kWave]; }
+};
+template <class V>
+struct LitePrm {
+    double dt, beta, gamma, sigma, b, epsilon, slo, ilo, alpha_min, alpha_max;
+    V v;
+    EPI_DEV double A(int k) const { return v.A(k); }
+    EPI_DEV double Umin(int k) const { return v.Umin(k); }
+    EPI_DEV double Umax(int k) const { return v.Umax(k); }
+    EPI_DEV double W(int k) const { return v.W(k); }
+};
+template <class V>
+EPI_DEV void load_lite(LitePrm<V> &p, const double *__restrict__ prm, int B, int c, int lo_is_zero)
+{
+    auto g = [&](int f) { return prm[(size_t)f * B + c]; };
+    p.dt = g(EPI_PRM_DT); p.beta = g(EPI_PRM_BETA); p.gamma = g(EPI_PRM_GAMMA);
+    p.sigma = g(EPI_PRM_SIGMA); p.b = g(EPI_PRM_B); p.epsilon = g(EPI_PRM_EPSILON);
+    p.slo = lo_is_zero ? 0.0 : g(EPI_PRM_S_MIN);
+    p.ilo = lo_is_zero ? 0.0 : g(EPI_PRM_I_MIN);
+    p.alpha_min = g(EPI_PRM_ALPHA_MIN); p.alpha_max = g(EPI_PRM_ALPHA_MAX);
+}
 
 // wave-uniform model switches (see MODEL_TABLE in epiekf.hip)
 struct ModelFlags {
@@ -112,8 +154,8 @@ EPI_DEV void symmetrize(double (&P)[M * M])  // (P + P')/2.0   GenericEKF.m:138,
 
 // ---- model callbacks -----------------------------------------------------
 // StateHardMargins: SIAlphaModelEKF.m:27-31, OptControlled.m:27-31, Backward*.m:48-52
-template <int M>
-EPI_DEV void state_hard_margins(const ChainPrm &p, double (&s)[M])
+template <int M, class PRM>
+EPI_DEV void state_hard_margins(const PRM &p, double (&s)[M])
 {
     s[0] = fmin(1.0, fmax(p.slo, s[0]));
     s[1] = fmin(1.0, fmax(p.ilo, s[1]));
@@ -121,17 +163,17 @@ EPI_DEV void state_hard_margins(const ChainPrm &p, double (&s)[M])
 }
 
 // bang-bang substitution of NaN controls: OptControlled.m:49-58 (strict >), NewCase...m:172-181 (>=)
-template <int M>
-EPI_DEV void resolve_control(const ChainPrm &p, const ModelFlags &mf, const double (&s)[M], double (&u)[kNpi])
+template <int M, class PRM>
+EPI_DEV void resolve_control(const PRM &p, const ModelFlags &mf, const double (&s)[M], double (&u)[kNpi])
 {
     if (M == 6) {
         const double gs6 = p.gamma * s[M == 6 ? 5 : 0];
 #pragma unroll
         for (int k = 0; k < kNpi; k++) {
             if (is_nan(u[k])) {
-                double phi = p.epsilon * p.w[k] - gs6 * p.a[k];
+                double phi = p.epsilon * p.W(k) - gs6 * p.A(k);
                 bool lo = mf.phi_ge ? (phi >= 0.0) : (phi > 0.0);
-                u[k] = lo ? p.u_min[k] : p.u_max[k];
+                u[k] = lo ? p.Umin(k) : p.Umax(k);
             }
         }
     }
@@ -139,15 +181,15 @@ EPI_DEV void resolve_control(const ChainPrm &p, const ModelFlags &mf, const doub
 
 // NlinStateUpdate: SIAlphaModelEKF.m:39-48, OptControlled.m:39-74, Backward*.m:60-95.
 // `u` comes in with NaNs and leaves as the control actually applied (u_opt).
-template <int M, int FLIP>
-EPI_DEV void nlin_state_update(const ChainPrm &p, const ModelFlags &mf, double (&u)[kNpi],
+template <int M, int FLIP, class PRM>
+EPI_DEV void nlin_state_update(const PRM &p, const ModelFlags &mf, double (&u)[kNpi],
                                const double (&s)[M], double (&sn)[M])
 {
     resolve_control<M>(p, mf, s, u);
     // params.gamma * params.a' * (params.u_max - u): row vector (gamma*a') times column
-    double dot = (p.gamma * p.a[0]) * (p.u_max[0] - u[0]);
+    double dot = (p.gamma * p.A(0)) * (p.Umax(0) - u[0]);
 #pragma unroll
-    for (int k = 1; k < kNpi; k++) dot = fma(p.gamma * p.a[k], p.u_max[k] - u[k], dot);
+    for (int k = 1; k < kNpi; k++) dot = fma(p.gamma * p.A(k), p.Umax(k) - u[k], dot);
     const double asi = s[2] * s[0] * s[1];
     const double f3 = -p.gamma * s[2] + p.gamma * p.b + dot;
     if (!FLIP) {
@@ -195,8 +237,8 @@ EPI_DEV void obs_jacobian(const ModelFlags &mf, const double (&s)[M], double (&C
 
 // StateJacobians: SIAlphaModelEKF.m:62-76, OptControlled.m:89-135, Backward*.m:83-97 / :109-156.
 // `u` is the ORIGINAL control column (NaNs kept), GenericEKF.m:157,206.
-template <int M, int FLIP>
-EPI_DEV void state_jacobians(const ChainPrm &p, const double (&u)[kNpi], const double (&s)[M], double (&A)[M * M])
+template <int M, int FLIP, class PRM>
+EPI_DEV void state_jacobians(const PRM &p, const double (&u)[kNpi], const double (&s)[M], double (&A)[M * M])
 {
     const double dt = p.dt;
 #pragma unroll
@@ -227,9 +269,9 @@ EPI_DEV void state_jacobians(const ChainPrm &p, const double (&u)[kNpi], const d
 #pragma unroll
         for (int k = 0; k < kNpi; k++) {
             if (is_nan(u[k])) {
-                double phi = p.epsilon * p.w[k] - gs6 * p.a[k];
+                double phi = p.epsilon * p.W(k) - gs6 * p.A(k);
                 if (phi > -inv_sigma && phi < inv_sigma) {
-                    double term = p.gamma * dt * (p.sigma / 2.0) * p.a[k] * (p.u_max[k] - p.u_min[k]);
+                    double term = p.gamma * dt * (p.sigma / 2.0) * p.A(k) * (p.Umax(k) - p.Umin(k));
                     a36 = FLIP ? (a36 + term) : (a36 - term);
                 }
             }

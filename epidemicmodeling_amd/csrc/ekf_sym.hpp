@@ -1,0 +1,446 @@
+// ekf_sym.hpp -- register-lean forward / backward kernels for the GenericExtendedKalmanFilter models.
+// Included from epiekf.hip inside namespace epi (after KArgs and the load/store helpers).
+//
+// Same arithmetic as the dense kernels (and the oracle), operation for operation, but
+//  * every covariance the generic filter carries is bit-wise symmetric (it is symmetrised at
+//    GenericEKF.m:138,161,226 and Ps_init is checked by ekf_precheck), so only the 21 (6) unique
+//    entries live in registers, packed upper-triangular;
+//  * terms that multiply a STRUCTURAL zero of the Jacobian A (SIAlphaModelEKFOptControlled.m:89-135:
+//    21 of 36 entries can be non-zero) or of (I - K C) (C(4:6) = 0, :138-148) are skipped.  For finite
+//    operands fma(a, 0, acc) == acc, so skipping them is exact; a chain whose covariance has overflowed
+//    to Inf/NaN can differ from the dense evaluation in WHERE the non-finite values sit (both are
+//    garbage there; status bit 0 / the J = 0 guard of :211 still fire) -- DESIGN.md "Arithmetic contract";
+//  * the four 12-vectors of `params` stay in memory (L2) / LDS instead of 96 VGPRs.
+// Net effect: <= 256 VGPRs, i.e. two waves per SIMD, so all B/64 waves of the headline sweep are
+// resident at once instead of running in two rounds.
+#pragma once
+
+template <int M> constexpr int nsym() { return M * (M + 1) / 2; }
+constexpr int sidx(int i, int j) { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; }
+
+// structural non-zero pattern of StateJacobians (same for the time-flipped twins)
+template <int M> constexpr bool a_nz(int i, int k)
+{
+    if (M == 3) return (i < 2) ? true : (k == 2);
+    return i == 0 ? (k < 3)
+         : i == 1 ? (k < 3)
+         : i == 2 ? (k == 2 || k == 5)
+         : i == 3 ? (k >= 1 && k <= 4)
+         : i == 4 ? (k == 0 || k == 2 || k == 3 || k == 4)
+                  : (k == 0 || k == 1 || k == 3 || k == 4 || k == 5);
+}
+
+template <int M>
+EPI_DEV void store_sym(double *__restrict__ dst, int t, int B, int c, const double (&P)[nsym<M>()])
+{
+    if (!dst) return;
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) dst[((size_t)t * (M * M) + IXM(i, j)) * B + c] = P[sidx(i, j)];
+}
+template <int M>
+EPI_DEV void load_sym(const double *__restrict__ src, int t, int B, int c, double (&P)[nsym<M>()])
+{
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i <= j; i++) P[sidx(i, j)] = src[((size_t)t * (M * M) + IXM(i, j)) * B + c];
+}
+
+// ---------------------------------------------------------------------------
+// pre-check: may this batch take the symmetric fast path?  (Ps_init bit-wise symmetric, Q_w diagonal)
+// ---------------------------------------------------------------------------
+template <int M>
+__global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restrict__ flag)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.B) return;
+    const int B = a.B;
+    bool dense = false;
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < j; i++) {
+            const double pu = a.Ps_init[(size_t)IXM(i, j) * B + c], pl = a.Ps_init[(size_t)IXM(j, i) * B + c];
+            const bool same = (pu == pl) || (is_nan(pu) && is_nan(pl));
+            const double qu = a.Q[(size_t)IXM(i, j) * B + c], ql = a.Q[(size_t)IXM(j, i) * B + c];
+            dense = dense || !same || !(qu == 0.0) || !(ql == 0.0);
+        }
+    if (dense) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------------------
+// forward pass, symmetric-packed
+// ---------------------------------------------------------------------------
+// Launch bounds.  Capping at two waves per SIMD (kWave, 2 => 256 VGPRs) makes hipcc 7.2 spill ~430-680 B
+// per lane to scratch, which measured slower (15.3 / 26.0 ms) than one spill-free wave per SIMD
+// (11.8 / 14.1 ms) on the headline sweep; see DESIGN.md "Occupancy and the wave-count quantum".
+#ifndef EPI_FWD_LB
+#define EPI_FWD_LB kWave
+#endif
+#ifndef EPI_BWD_LB
+#define EPI_BWD_LB kWave
+#endif
+template <int M, int FLIP>
+__global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const int *__restrict__ dense_flag)
+{
+    extern __shared__ double lds[];   // three sliding windows [3][L][64], one column per lane
+    if (*dense_flag) return;          // ekf_fwd (dense) runs instead
+    constexpr int NS = nsym<M>();
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * kWave + lane;
+    if (c >= a.B) return;
+    const int B = a.B, T = a.T, L = a.L;
+    const int sx = a.x_series ? a.x_series[c] : c;
+    const int su = a.u_series ? a.u_series[c] : c;
+
+    LitePrm<VecGlobal> p;
+    load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
+    p.v.prm = a.prm; p.v.B = B; p.v.c = c;
+    const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
+    const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
+    const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
+
+    double sk_minus[M], Pm[NS], Qd[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        sk_minus[i] = a.s_init[(size_t)i * B + c];
+        Qd[i] = a.Q[(size_t)IXM(i, i) * B + c];
+    }
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i <= j; i++) Pm[sidx(i, j)] = a.Ps_init[(size_t)IXM(i, j) * B + c];
+
+    double *winMean = lds + lane, *winCov = lds + (size_t)L * kWave + lane, *winCovN = lds + (size_t)2 * L * kWave + lane;
+    for (int j = 0; j < L; j++) { winMean[j * kWave] = 0.0; winCov[j * kWave] = 0.0; winCovN[j * kWave] = 0.0; }
+    int head = 0;
+    const bool fixed_R = (a.r_mode == 0);
+    const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
+    double R_next = R_v;
+
+    for (int k = 0; k < T; k++) {
+        const int t = tpos<FLIP>(k, T);
+        const double Rk = fixed_R ? R_next : a.R_series[(size_t)k * a.Sx + sx];
+        const double xk = a.x[(size_t)t * a.Sx + sx];
+        double u_in[kNpi];
+        load_u(a, t, su, u_in);
+
+        store_vec<M>(a.S_MINUS, t, B, c, sk_minus);
+        store_sym<M>(a.P_MINUS, t, B, c, Pm);
+
+        double C[M];
+        obs_jacobian<M>(a.mf, sk_minus, C);                 // C(4:6) == 0 for m = 6
+        const double xk_minus = predict_obs<M>(a.mf, sk_minus, v_bar);
+
+        double innov, K[M], sk_plus[M], Pp[NS];
+        const bool valid = !is_nan(xk);
+        if (valid) {
+            innov = xk - xk_minus;
+            // P C' (== (C P)' bit for bit, P symmetric); only C(1:3) can be non-zero
+            double PCt[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double acc = Pm[sidx(i, 0)] * C[0];
+                acc = fma(Pm[sidx(i, 1)], C[1], acc);
+                acc = fma(Pm[sidx(i, 2)], C[2], acc);
+                PCt[i] = acc;
+            }
+            double CPCt = PCt[0] * C[0];
+            CPCt = fma(PCt[1], C[1], CPCt);
+            CPCt = fma(PCt[2], C[2], CPCt);
+            const double den = CPCt + gamma * Rk;
+#pragma unroll
+            for (int i = 0; i < M; i++) K[i] = PCt[i] / den;
+            // (I - K C): columns 4..6 are exactly those of the identity
+            double IKC[M][3];
+#pragma unroll
+            for (int i = 0; i < M; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) IKC[i][j] = ((i == j) ? 1.0 : 0.0) - K[i] * C[j];
+            // P+ = sym(((I - K C) P (I - K C)' + K R K') / gamma), one ROW of the Joseph form at a time: row i of
+            // T1 = (I - K C) P is formed, consumed into row i of the full result F, and as soon as both
+            // F(i,j) and F(j,i) exist they are averaged into the packed P+ -- at most one 6-vector of T1 and
+            // the not-yet-paired upper entries of F are live, instead of two full 6 x 6 temporaries
+            double F[M * M];
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double T1r[M];
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    double acc = IKC[i][0] * Pm[sidx(0, j)];
+                    acc = fma(IKC[i][1], Pm[sidx(1, j)], acc);
+                    acc = fma(IKC[i][2], Pm[sidx(2, j)], acc);
+                    if (i >= 3) acc = acc + Pm[sidx(i, j)];          // + 1 * P(i,j)
+                    T1r[j] = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    double acc = T1r[0] * IKC[j][0];
+                    acc = fma(T1r[1], IKC[j][1], acc);
+                    acc = fma(T1r[2], IKC[j][2], acc);
+                    if (j >= 3) acc = acc + T1r[j];
+                    F[IXM(i, j)] = (acc + (K[i] * Rk) * K[j]) / gamma;
+                }
+#pragma unroll
+                for (int j = 0; j < i; j++) Pp[sidx(j, i)] = (F[IXM(i, j)] + F[IXM(j, i)]) / 2.0;
+                Pp[sidx(i, i)] = (F[IXM(i, i)] + F[IXM(i, i)]) / 2.0;
+            }
+#pragma unroll
+            for (int i = 0; i < M; i++) sk_plus[i] = sk_minus[i] + K[i] * innov;
+        } else {
+            innov = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) { K[i] = 0.0; sk_plus[i] = sk_minus[i]; }
+#pragma unroll
+            for (int e = 0; e < NS; e++) Pp[e] = Pm[e];
+        }
+        state_hard_margins<M>(p, sk_plus);
+
+        double u_app[kNpi];
+#pragma unroll
+        for (int q = 0; q < kNpi; q++) u_app[q] = u_in[q];
+        nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
+        store_u(a.u_opt, a, t, c, u_app);
+        {
+            double A[M * M], G[M * M];
+            state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
+            // P- = sym(A P+ A' + Q), Q diagonal; row by row as above, structural zeros of A skipped
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double T1r[M];
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    double acc = 0.0;
+                    bool first = true;
+#pragma unroll
+                    for (int q = 0; q < M; q++)
+                        if (a_nz<M>(i, q)) {
+                            acc = first ? A[IXM(i, q)] * Pp[sidx(q, j)] : fma(A[IXM(i, q)], Pp[sidx(q, j)], acc);
+                            first = false;
+                        }
+                    T1r[j] = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    double acc = 0.0;
+                    bool first = true;
+#pragma unroll
+                    for (int q = 0; q < M; q++)
+                        if (a_nz<M>(j, q)) {
+                            acc = first ? T1r[q] * A[IXM(j, q)] : fma(T1r[q], A[IXM(j, q)], acc);
+                            first = false;
+                        }
+                    G[IXM(i, j)] = acc + ((i == j) ? Qd[i] : 0.0);
+                }
+#pragma unroll
+                for (int j = 0; j < i; j++) Pm[sidx(j, i)] = (G[IXM(i, j)] + G[IXM(j, i)]) / 2.0;
+                Pm[sidx(i, i)] = (G[IXM(i, i)] + G[IXM(i, i)]) / 2.0;
+            }
+        }
+        state_hard_margins<M>(p, sk_minus);
+
+        store_vec<M>(a.S_PLUS, t, B, c, sk_plus);
+        store_sym<M>(a.P_PLUS, t, B, c, Pp);
+        store_vec<M>(a.K_GAIN, t, B, c, K);
+        if (a.innovations) a.innovations[(size_t)t * B + c] = innov;
+
+        // innovation monitor (identical to ekf_fwd)
+        const int cnt = (k + 1 < L) ? (k + 1) : L;
+        head = (head == 0) ? (L - 1) : (head - 1);
+        winMean[head * kWave] = innov;
+        double sum = innov;
+        {
+            int idx = head;
+            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sum = sum + winMean[idx * kWave]; }
+        }
+        const double mu = sum / (double)cnt;
+        const double cc = (innov - mu) * (innov - mu);
+        const double ccn = cc / (Rk + kEps);
+        winCov[head * kWave] = cc;
+        winCovN[head * kWave] = ccn;
+        double sumN = ccn;
+        {
+            int idx = head;
+            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumN = sumN + winCovN[idx * kWave]; }
+        }
+        if (a.rho) a.rho[(size_t)t * B + c] = sumN / (double)cnt;
+        if (fixed_R) {
+            if (beta != 1.0 && valid && k < T - 1) {
+                double sumC = cc;
+                int idx = head;
+                for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumC = sumC + winCov[idx * kWave]; }
+                R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);
+            } else {
+                R_next = R_v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward recursion, symmetric-packed (X = pinv(P_MINUS) comes from eks_pinv)
+// ---------------------------------------------------------------------------
+template <int M, int FLIP>
+__global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const int *__restrict__ dense_flag)
+{
+    __shared__ double vlds[4 * kNpi * kWave];   // a, u_min, u_max, w: one column per lane
+    if (*dense_flag) return;
+    constexpr int NS = nsym<M>();
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * kWave + lane;
+    if (c >= a.B) return;
+    const int B = a.B, T = a.T;
+    const int su = a.u_series ? a.u_series[c] : c;
+    LitePrm<VecLds> p;
+    load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
+    p.v.base = vlds + lane;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) {
+        vlds[(0 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_A + k) * B + c];
+        vlds[(1 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
+        vlds[(2 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
+        vlds[(3 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+    }
+
+    // terminal conditions GenericEKF.m:189-202.  Ps_final is applied entry by entry, so P_SMOOTH(:,:,T)
+    // is only symmetric if Ps_final is: it is kept as a full matrix for the first step.
+    double Ss[M], Ps[NS];
+    const int tT = tpos<FLIP>(T - 1, T);
+    load_vec<M>(a.S_PLUS, tT, B, c, Ss);
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const double f = a.s_final[(size_t)i * B + c];
+        if (!is_nan(f)) Ss[i] = f;
+    }
+    double PsT[M * M];
+    load_mat<M>(a.P_PLUS, tT, B, c, PsT);
+#pragma unroll
+    for (int e = 0; e < M * M; e++) {
+        const double f = a.Ps_final[(size_t)e * B + c];
+        if (!is_nan(f)) PsT[e] = f;
+    }
+    store_vec<M>(a.S_SMOOTH, tT, B, c, Ss);
+    store_mat<M>(a.P_SMOOTH, tT, B, c, PsT);
+    if (a.u_opt_smooth) {
+        double z[kNpi];
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) z[k] = 0.0;
+        store_u(a.u_opt_smooth, a, tT, c, z);
+    }
+    if (a.pinv_rank) a.pinv_rank[(size_t)tT * B + c] = -1;
+
+    int st_guard = 0, st_cap = 0, min_rank = M;
+    for (int k = T - 2; k >= 0; k--) {
+        const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
+        const bool first_step = (k == T - 2);
+        double Sp[M], Pp[NS], u_in[kNpi];
+        load_vec<M>(a.S_PLUS, t, B, c, Sp);
+        load_sym<M>(a.P_PLUS, t, B, c, Pp);
+        load_u(a, t, su, u_in);
+
+        double J[M * M];
+        int rank = -1;
+        {
+            const int rk = a.rankbuf[(size_t)t1 * B + c];
+            if (rk < 0) {
+#pragma unroll
+                for (int e = 0; e < M * M; e++) J[e] = 0.0;
+                st_guard = 1;
+            } else {
+                double A[M * M], PAt[M * M];
+                state_jacobians<M, FLIP>(p, u_in, Sp, A);
+                // P+ A'  (zeros of A skipped)
+#pragma unroll
+                for (int j = 0; j < M; j++)
+#pragma unroll
+                    for (int i = 0; i < M; i++) {
+                        double acc = 0.0;
+                        bool first = true;
+#pragma unroll
+                        for (int q = 0; q < M; q++)
+                            if (a_nz<M>(j, q)) {
+                                acc = first ? Pp[sidx(i, q)] * A[IXM(j, q)] : fma(Pp[sidx(i, q)], A[IXM(j, q)], acc);
+                                first = false;
+                            }
+                        PAt[IXM(i, j)] = acc;
+                    }
+                double X[M * M];
+                load_mat<M>(a.X, t1, B, c, X);
+                mat_mul<M>(PAt, X, J);
+                rank = rk & 0xff;
+                st_cap |= (rk >> 8) & 1;
+                min_rank = rank < min_rank ? rank : min_rank;
+            }
+        }
+        if (a.pinv_rank) a.pinv_rank[(size_t)t * B + c] = rank;
+
+        double Sm1[M], Sn[M];
+        load_vec<M>(a.S_MINUS, t1, B, c, Sm1);
+        {
+            double dv[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) dv[i] = Ss[i] - Sm1[i];
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double acc = J[IXM(i, 0)] * dv[0];
+#pragma unroll
+                for (int j = 1; j < M; j++) acc = fma(J[IXM(i, j)], dv[j], acc);
+                Sn[i] = Sp[i] + acc;
+            }
+        }
+        state_hard_margins<M>(p, Sn);
+        {
+            // D = P_MINUS(k+1) - P_SMOOTH(k+1); symmetric except possibly at the first step (Ps_final)
+            double T1[M * M];
+            if (first_step) {
+                double D[M * M];
+#pragma unroll
+                for (int j = 0; j < M; j++)
+#pragma unroll
+                    for (int i = 0; i < M; i++)
+                        D[IXM(i, j)] = a.P_MINUS[((size_t)t1 * (M * M) + IXM(i, j)) * B + c] - PsT[IXM(i, j)];
+                mat_mul<M>(J, D, T1);
+            } else {
+                double D[NS];
+                load_sym<M>(a.P_MINUS, t1, B, c, D);
+#pragma unroll
+                for (int e = 0; e < NS; e++) D[e] = D[e] - Ps[e];
+#pragma unroll
+                for (int j = 0; j < M; j++)
+#pragma unroll
+                    for (int i = 0; i < M; i++) {
+                        double acc = J[IXM(i, 0)] * D[sidx(0, j)];
+#pragma unroll
+                        for (int q = 1; q < M; q++) acc = fma(J[IXM(i, q)], D[sidx(q, j)], acc);
+                        T1[IXM(i, j)] = acc;
+                    }
+            }
+            // P_SMOOTH(k) = sym(P+ - T1 J')
+            auto smooth = [&](int i, int j) -> double {
+                double acc = T1[IXM(i, 0)] * J[IXM(j, 0)];
+#pragma unroll
+                for (int q = 1; q < M; q++) acc = fma(T1[IXM(i, q)], J[IXM(j, q)], acc);
+                return Pp[sidx(i, j)] - acc;
+            };
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+#pragma unroll
+                for (int i = 0; i < j; i++) Ps[sidx(i, j)] = (smooth(j, i) + smooth(i, j)) / 2.0;
+                const double dj = smooth(j, j);
+                Ps[sidx(j, j)] = (dj + dj) / 2.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) Ss[i] = Sn[i];
+        store_vec<M>(a.S_SMOOTH, t, B, c, Ss);
+        store_sym<M>(a.P_SMOOTH, t, B, c, Ps);
+        if (a.u_opt_smooth) {
+            double sn_unused[M];
+            nlin_state_update<M, FLIP>(p, a.mf, u_in, Ss, sn_unused);
+            store_u(a.u_opt_smooth, a, t, c, u_in);
+        }
+    }
+    if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+}

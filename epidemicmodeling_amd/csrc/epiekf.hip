@@ -42,6 +42,9 @@ struct KArgs {
     double *X;
     int32_t *rankbuf;
     int pinv_pos0;
+    // generic models: word set by ekf_precheck when the batch must take the dense kernels (non-symmetric
+    // Ps_init or non-diagonal Q_w); NULL = dense kernels always run (NewCase models)
+    int *dense_flag;
 };
 
 // position in the caller's time axis of filter step k (flipped wrappers run the
@@ -95,6 +98,7 @@ template <int M, int FLIP, int GENERIC>
 __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 {
     extern __shared__ double lds[];   // three sliding windows [3][L][64], one column per lane
+    if (a.dense_flag && !*a.dense_flag) return;   // the symmetric fast path (ekf_fwd_sym) handles this batch
     const int lane = threadIdx.x;
     const int c = blockIdx.x * kWave + lane;
     if (c >= a.B) return;
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
 template <int M, int FLIP, int GENERIC>
 __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 {
+    if (a.dense_flag && !*a.dense_flag) return;   // eks_bwd_sym handles this batch
     const int c = blockIdx.x * kWave + threadIdx.x;
     if (c >= a.B) return;
     const int B = a.B, T = a.T;
@@ -425,6 +430,8 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
     }
     if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }
+
+#include "ekf_sym.hpp"
 
 // ---------------------------------------------------------------------------
 // forward simulators
@@ -561,7 +568,7 @@ static int hip_fail(char *err, hipError_t e, const char *what)
     return EPI_ERR_HIP;
 }
 
-struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, total; };
+struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, total; };
 static WsLayout ws_layout(const epi_batch_desc *d)
 {
     const int m = MODEL_TABLE[d->model].m;
@@ -577,6 +584,7 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     const bool generic = MODEL_TABLE[d->model].generic;
     w.x = take(generic, nP);
     w.rank = take(generic, (size_t)d->T * d->B * sizeof(int32_t));
+    w.flag = take(generic, 256);
     w.total = off;
     return w;
 }
@@ -593,6 +601,20 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, hipStrea
             e = hipFuncSetAttribute((const void *)ekf_fwd<M, FLIP, GENERIC>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             if (e != hipSuccess) return e;
+            if (GENERIC) {
+                e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                if (e != hipSuccess) return e;
+            }
+        }
+        if (GENERIC) {
+            // fast path unless ekf_precheck finds a non-symmetric Ps_init / non-diagonal Q_w in the batch;
+            // both variants are enqueued, the one that is not selected returns at once
+            if ((e = hipMemsetAsync(ka.dense_flag, 0, sizeof(int), st)) != hipSuccess) return e;
+            hipLaunchKernelGGL((ekf_precheck<M>), dim3((ka.B + 255) / 256), dim3(256), 0, st, ka, ka.dense_flag);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -604,6 +626,10 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, hipStrea
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phase == 0 || phase == 2 || phase == 4) {
+        if (GENERIC) {
+            hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
         hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
         e = hipGetLastError();
     }
@@ -713,6 +739,7 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     ka.X = mi.generic ? (double *)(ws + wl.x) : nullptr;
     ka.rankbuf = mi.generic ? (int32_t *)(ws + wl.rank) : nullptr;
     ka.pinv_pos0 = mi.flipped ? 0 : 1;
+    ka.dense_flag = mi.generic ? (int *)(ws + wl.flag) : nullptr;
     {
         struct { uint32_t bit; const void *p; const char *n; } chk[] = {
             {EPI_OUT_U_OPT, out->u_opt, "u_opt"}, {EPI_OUT_S_MINUS, out->S_MINUS, "S_MINUS"},

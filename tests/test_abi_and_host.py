@@ -76,12 +76,17 @@ def test_validate_accepts_order_two_and_codegen_ignores_obs_type(hip_lib):
 
 
 def test_workspace_covers_unselected_forward_quantities(hip_lib):
+    r256 = lambda n: (n + 255) // 256 * 256
+    # smoother intermediates every generic-model run needs: X = pinv(P_MINUS) [T][36][B], rank words, flag
+    base = r256(4 * 10 * 8 * 36) + r256(4 * 10 * 4) + 256
     full = hip_lib.epi_ekf_workspace_bytes(C.byref(_desc(model="SIAlphaModelEKFOptControlled")))
-    assert full == 0
+    assert full == base
     red = _desc(model="SIAlphaModelEKFOptControlled", out_mask=L.OUT_BITS["u_opt_smooth"] | L.OUT_BITS["S_SMOOTH"])
-    need = 4 * 10 * 8 * (6 + 6 + 36 + 36)
+    need = base + 4 * 10 * 8 * (6 + 6 + 36 + 36)
     got = hip_lib.epi_ekf_workspace_bytes(C.byref(red))
     assert need <= got <= need + 4 * 256
+    # the NewCase models solve with mrdivide inside the recursion: no intermediates
+    assert hip_lib.epi_ekf_workspace_bytes(C.byref(_desc(model="NewCaseEKFEstimatorWithOptimalNPI", r_mode=0))) == 0
 
 
 def test_run_device_argument_checks_without_gpu(hip_lib):
