@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg3", "cfg5"])
     ap.add_argument("--outputs", default="all", choices=["all", "reduced"],
                     help="reduced = u_opt_smooth + S_SMOOTH only (what TrainPredictPrescribeNPI.m:460-493 consumes)")
+    ap.add_argument("--chunks", type=int, default=8,
+                    help="chain chunks a full call is split into (helper streams; DESIGN.md); 0/1 = single stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chains", type=int, default=0, help="0 = sized for ~15 s")
     return ap.parse_args()
@@ -112,14 +114,14 @@ def main():
     m = w.m
     outputs = None if args.outputs == "all" else ["u_opt_smooth", "S_SMOOTH"]
     dw = batch.DeviceWorkload(w, dev)
-    runner = batch.EkfRunner(dw, outputs=outputs, extras=False)
+    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks)
     steps_per_pass = w.B * w.T
     t_hist_idx = w.meta.get("T_hist", w.T) - 1
 
     def one_step(events=None):
         if events is None:
-            runner.run()
-        else:
+            runner.run()                      # the call a user makes: forward + pinv + backward
+        else:                                 # same work, one kernel stage per call, bracketed by HIP events
             e0, e1, e2, e3 = events
             e0.record(); runner.run(phase=1); e1.record(); runner.run(phase=3); e2.record()
             runner.run(phase=4); e3.record()
@@ -130,13 +132,12 @@ def main():
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(evs[k])
+        one_step()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -145,6 +146,11 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # per-kernel durations: the same K steps again, stage by stage, HIP events on the launch stream
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    for k in range(args.steps):
+        one_step(evs[k])
+    torch.cuda.synchronize(dev)
 
     ms_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     ms_pinv = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
@@ -168,7 +174,7 @@ def main():
             "value": value, "unit": "region-day EKF steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs,
+            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "chunks": args.chunks,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
                        "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather to rank 0"},

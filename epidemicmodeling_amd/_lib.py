@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libepiekf.so")
 
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
-    "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_seirp_sim_device",
+    "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_seirp_sim_device",
 ]
 
 
@@ -30,7 +30,7 @@ class EpiError(RuntimeError):
 class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "model", "B", "T", "Sx", "Su", "n_npi", "L", "order",
                                           "obs_type", "r_mode", "q_mode")] + [
-        ("out_mask", C.c_uint32), ("phase", C.c_int32)]
+        ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("chunks", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -85,6 +85,9 @@ def lib():
         h.epi_ekf_validate.argtypes = [C.POINTER(BatchDesc), C.c_char_p]
         h.epi_ekf_workspace_bytes.restype = C.c_size_t
         h.epi_ekf_workspace_bytes.argtypes = [C.POINTER(BatchDesc)]
+        h.epi_ekf_precheck_device.restype = C.c_int
+        h.epi_ekf_precheck_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.c_void_p, C.POINTER(C.c_int),
+                                              C.c_char_p]
         h.epi_ekf_run_device.restype = C.c_int
         h.epi_ekf_run_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_char_p]
@@ -119,4 +122,5 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask)
     else:
         d.obs_type = int(obs_type)
     d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), 0, int(out_mask), 0
+    d.path_hint, d.chunks = 0, 0
     return d

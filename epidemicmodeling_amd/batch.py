@@ -60,7 +60,11 @@ class DeviceWorkload:
 class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
-    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False):
+    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True):
+        """chunks > 1: a full run() is split into that many chain chunks on helper streams (overlaps the
+        (chain, step)-parallel pinv grid with the sequential kernels of the other chunks).  precheck: ask the
+        library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
+        run() enqueues only the variant that will actually execute."""
         self.dw = dw
         names = list(OUT_NAMES) if outputs is None else list(outputs)
         if dw.model.startswith("NewCase") and "u_opt_smooth" in names:
@@ -83,6 +87,14 @@ class EkfRunner:
         self.ws_bytes = int(h.epi_ekf_workspace_bytes(C.byref(self.desc)))
         self.ws = torch.empty((max(self.ws_bytes, 8) + 7) // 8, dtype=torch.float64, device=dev)
         self.ins = dw.inputs_struct()
+        self.desc.chunks = int(chunks)
+        if precheck:
+            ok = C.c_int(0)
+            st = torch.cuda.current_stream(dev)
+            rc = h.epi_ekf_precheck_device(C.byref(self.desc), C.byref(self.ins), C.c_void_p(st.cuda_stream),
+                                           C.byref(ok), self.err)
+            _lib.check(rc, self.err)
+            self.desc.path_hint = 1 if ok.value else 2
         self.outs = _lib.Outputs()
         for n in OUT_NAMES:
             setattr(self.outs, n, _ptr(self.out.get(n)))
@@ -103,10 +115,10 @@ class EkfRunner:
         return sum(t.numel() * 8 for t in self.out.values())
 
 
-def run_workload(w, outputs=None, device="cuda:0", extras=True):
+def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True):
     """Convenience: upload `w`, run once, return dict name -> numpy array (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
-    r = EkfRunner(dw, outputs, extras=extras)
+    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck)
     r.run()
     torch.cuda.synchronize(dw.device)
     res = {n: t.cpu().numpy() for n, t in r.out.items()}

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/epiekf.h"
 
 namespace epi {

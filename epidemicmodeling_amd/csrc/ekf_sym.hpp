@@ -52,8 +52,9 @@ EPI_DEV void load_sym(const double *__restrict__ src, int t, int B, int c, doubl
 // pre-check: may this batch take the symmetric fast path?  (Ps_init bit-wise symmetric, Q_w diagonal)
 // ---------------------------------------------------------------------------
 template <int M>
-__global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restrict__ flag)
+__global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restrict__ flag, int force_dense)
 {
+    if (force_dense) { if (blockIdx.x == 0 && threadIdx.x == 0) *flag = 1; return; }
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.B) return;
     const int B = a.B;
@@ -89,15 +90,14 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     if (*dense_flag) return;          // ekf_fwd (dense) runs instead
     constexpr int NS = nsym<M>();
     const int lane = threadIdx.x;
-    const int c = blockIdx.x * kWave + lane;
-    if (c >= a.B) return;
+    const int c = a.c0 + blockIdx.x * kWave + lane;
+    if (c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
 
-    LitePrm<VecGlobal> p;
-    load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
-    p.v.prm = a.prm; p.v.B = B; p.v.c = c;
+    ChainPrm p;                       // one wave per SIMD: there is room for the 12-vectors in VGPRs
+    load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero);
     const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
     const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
     const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
@@ -120,12 +120,27 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
     double R_next = R_v;
 
+    // Software pipeline of the inputs.  Vector-memory operations retire in issue order (one vmcnt), so a
+    // load issued after a step's ~100 stores would wait for all of them to drain; the inputs of step k+1 are
+    // therefore requested at the top of step k, ahead of its stores, and consumed one iteration later.
+    double x_nxt = a.x[(size_t)tpos<FLIP>(0, T) * a.Sx + sx];
+    double r_nxt = fixed_R ? 0.0 : a.R_series[sx];
+    double u_nxt[kNpi];
+    load_u(a, tpos<FLIP>(0, T), su, u_nxt);
+
     for (int k = 0; k < T; k++) {
         const int t = tpos<FLIP>(k, T);
-        const double Rk = fixed_R ? R_next : a.R_series[(size_t)k * a.Sx + sx];
-        const double xk = a.x[(size_t)t * a.Sx + sx];
+        const double Rk = fixed_R ? R_next : r_nxt;
+        const double xk = x_nxt;
         double u_in[kNpi];
-        load_u(a, t, su, u_in);
+#pragma unroll
+        for (int q = 0; q < kNpi; q++) u_in[q] = u_nxt[q];
+        if (k + 1 < T) {
+            const int tn = tpos<FLIP>(k + 1, T);
+            x_nxt = a.x[(size_t)tn * a.Sx + sx];
+            if (!fixed_R) r_nxt = a.R_series[(size_t)(k + 1) * a.Sx + sx];
+            load_u(a, tn, su, u_nxt);
+        }
 
         store_vec<M>(a.S_MINUS, t, B, c, sk_minus);
         store_sym<M>(a.P_MINUS, t, B, c, Pm);
@@ -282,6 +297,11 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
 // ---------------------------------------------------------------------------
 // backward recursion, symmetric-packed (X = pinv(P_MINUS) comes from eks_pinv)
 // ---------------------------------------------------------------------------
+template <int M>
+struct BwdIn {   // everything smoother step k reads: forward quantities of steps k and k+1
+    double Sp[M], Pp[M * (M + 1) / 2], u[kNpi], X[M * M], Sm1[M], Pm1[M * (M + 1) / 2];
+    int rk;
+};
 template <int M, int FLIP>
 __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
@@ -289,8 +309,8 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     if (*dense_flag) return;
     constexpr int NS = nsym<M>();
     const int lane = threadIdx.x;
-    const int c = blockIdx.x * kWave + lane;
-    if (c >= a.B) return;
+    const int c = a.c0 + blockIdx.x * kWave + lane;
+    if (c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     LitePrm<VecLds> p;
@@ -332,115 +352,141 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     if (a.pinv_rank) a.pinv_rank[(size_t)tT * B + c] = -1;
 
     int st_guard = 0, st_cap = 0, min_rank = M;
-    for (int k = T - 2; k >= 0; k--) {
+    // Software pipeline.  Vector-memory operations retire in issue order, so loads issued after a step's
+    // stores would wait for those stores to drain.  The results of a step are therefore kept in registers
+    // (they are the recursion state anyway) and stored at the top of the NEXT iteration, right after that
+    // iteration's loads have been issued.
+    BwdIn<M> cur;
+    auto fetch = [&](int k, BwdIn<M> &d) {
         const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
-        const bool first_step = (k == T - 2);
-        double Sp[M], Pp[NS], u_in[kNpi];
-        load_vec<M>(a.S_PLUS, t, B, c, Sp);
-        load_sym<M>(a.P_PLUS, t, B, c, Pp);
-        load_u(a, t, su, u_in);
+        load_vec<M>(a.S_PLUS, t, B, c, d.Sp);
+        load_sym<M>(a.P_PLUS, t, B, c, d.Pp);
+        load_u(a, t, su, d.u);
+        d.rk = a.rankbuf[(size_t)t1 * B + c];
+        load_mat<M>(a.X, t1, B, c, d.X);          // unused garbage where the :211 guard fired (rk < 0)
+        load_vec<M>(a.S_MINUS, t1, B, c, d.Sm1);
+        load_sym<M>(a.P_MINUS, t1, B, c, d.Pm1);
+    };
+    int t_pend = -1, rank_pend = -1;
+    double u_pend[kNpi];
+#pragma unroll
+    for (int q = 0; q < kNpi; q++) u_pend[q] = 0.0;
+    auto flush = [&]() {          // store the previous step's results (Ss, Ps still hold them)
+        if (t_pend < 0) return;
+        if (a.pinv_rank) a.pinv_rank[(size_t)t_pend * B + c] = rank_pend;
+        store_vec<M>(a.S_SMOOTH, t_pend, B, c, Ss);
+        store_sym<M>(a.P_SMOOTH, t_pend, B, c, Ps);
+        if (a.u_opt_smooth) store_u(a.u_opt_smooth, a, t_pend, c, u_pend);
+    };
 
+    auto step = [&](int k, auto first_tag) {
+        constexpr bool first_step = decltype(first_tag)::value;
+        const int t = tpos<FLIP>(k, T);
+        fetch(k, cur);
+        flush();
         double J[M * M];
         int rank = -1;
-        {
-            const int rk = a.rankbuf[(size_t)t1 * B + c];
-            if (rk < 0) {
+        if (cur.rk < 0) {                                      // non-finite P_MINUS guard :211-213
 #pragma unroll
-                for (int e = 0; e < M * M; e++) J[e] = 0.0;
-                st_guard = 1;
-            } else {
-                double A[M * M], PAt[M * M];
-                state_jacobians<M, FLIP>(p, u_in, Sp, A);
-                // P+ A'  (zeros of A skipped)
+            for (int e = 0; e < M * M; e++) J[e] = 0.0;
+            st_guard = 1;
+        } else {
+            double A[M * M];
+            state_jacobians<M, FLIP>(p, cur.u, cur.Sp, A);     // :206
+            // J = (P+ A') X  :215, one row at a time (zeros of A skipped): row i of P+ A' is consumed into
+            // row i of J at once, so the 6 x 6 product P+ A' is never live as a whole
 #pragma unroll
-                for (int j = 0; j < M; j++)
+            for (int i = 0; i < M; i++) {
+                double PAr[M];
 #pragma unroll
-                    for (int i = 0; i < M; i++) {
-                        double acc = 0.0;
-                        bool first = true;
+                for (int j = 0; j < M; j++) {
+                    double acc = 0.0;
+                    bool first = true;
 #pragma unroll
-                        for (int q = 0; q < M; q++)
-                            if (a_nz<M>(j, q)) {
-                                acc = first ? Pp[sidx(i, q)] * A[IXM(j, q)] : fma(Pp[sidx(i, q)], A[IXM(j, q)], acc);
-                                first = false;
-                            }
-                        PAt[IXM(i, j)] = acc;
-                    }
-                double X[M * M];
-                load_mat<M>(a.X, t1, B, c, X);
-                mat_mul<M>(PAt, X, J);
-                rank = rk & 0xff;
-                st_cap |= (rk >> 8) & 1;
-                min_rank = rank < min_rank ? rank : min_rank;
+                    for (int q = 0; q < M; q++)
+                        if (a_nz<M>(j, q)) {
+                            acc = first ? cur.Pp[sidx(i, q)] * A[IXM(j, q)] : fma(cur.Pp[sidx(i, q)], A[IXM(j, q)], acc);
+                            first = false;
+                        }
+                    PAr[j] = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    double acc = PAr[0] * cur.X[IXM(0, j)];
+#pragma unroll
+                    for (int q = 1; q < M; q++) acc = fma(PAr[q], cur.X[IXM(q, j)], acc);
+                    J[IXM(i, j)] = acc;
+                }
             }
+            rank = cur.rk & 0xff;
+            st_cap |= (cur.rk >> 8) & 1;
+            min_rank = rank < min_rank ? rank : min_rank;
         }
-        if (a.pinv_rank) a.pinv_rank[(size_t)t * B + c] = rank;
-
-        double Sm1[M], Sn[M];
-        load_vec<M>(a.S_MINUS, t1, B, c, Sm1);
+        double Sn[M];
         {
             double dv[M];
 #pragma unroll
-            for (int i = 0; i < M; i++) dv[i] = Ss[i] - Sm1[i];
+            for (int i = 0; i < M; i++) dv[i] = Ss[i] - cur.Sm1[i];
 #pragma unroll
             for (int i = 0; i < M; i++) {
                 double acc = J[IXM(i, 0)] * dv[0];
 #pragma unroll
                 for (int j = 1; j < M; j++) acc = fma(J[IXM(i, j)], dv[j], acc);
-                Sn[i] = Sp[i] + acc;
+                Sn[i] = cur.Sp[i] + acc;                       // :218
             }
         }
-        state_hard_margins<M>(p, Sn);
+        state_hard_margins<M>(p, Sn);                          // :221
         {
-            // D = P_MINUS(k+1) - P_SMOOTH(k+1); symmetric except possibly at the first step (Ps_final)
-            double T1[M * M];
+            // P_SMOOTH(k) = sym(P+ - (J D) J'),  D = P_MINUS(k+1) - P_SMOOTH(k+1)   :223-226
+            // D is symmetric except possibly at the first step (Ps_final overrides); rows of J D are consumed
+            // one at a time and paired entries are averaged as soon as both exist (see ekf_fwd_sym)
+            double Dfull[first_step ? M * M : 1], Dsym[first_step ? 1 : NS];
             if (first_step) {
-                double D[M * M];
 #pragma unroll
                 for (int j = 0; j < M; j++)
 #pragma unroll
-                    for (int i = 0; i < M; i++)
-                        D[IXM(i, j)] = a.P_MINUS[((size_t)t1 * (M * M) + IXM(i, j)) * B + c] - PsT[IXM(i, j)];
-                mat_mul<M>(J, D, T1);
+                    for (int i = 0; i < M; i++) Dfull[IXM(i, j)] = cur.Pm1[sidx(i, j)] - PsT[IXM(i, j)];
             } else {
-                double D[NS];
-                load_sym<M>(a.P_MINUS, t1, B, c, D);
 #pragma unroll
-                for (int e = 0; e < NS; e++) D[e] = D[e] - Ps[e];
-#pragma unroll
-                for (int j = 0; j < M; j++)
-#pragma unroll
-                    for (int i = 0; i < M; i++) {
-                        double acc = J[IXM(i, 0)] * D[sidx(0, j)];
-#pragma unroll
-                        for (int q = 1; q < M; q++) acc = fma(J[IXM(i, q)], D[sidx(q, j)], acc);
-                        T1[IXM(i, j)] = acc;
-                    }
+                for (int e = 0; e < NS; e++) Dsym[e] = cur.Pm1[e] - Ps[e];
             }
-            // P_SMOOTH(k) = sym(P+ - T1 J')
-            auto smooth = [&](int i, int j) -> double {
-                double acc = T1[IXM(i, 0)] * J[IXM(j, 0)];
+            double F[M * M];
 #pragma unroll
-                for (int q = 1; q < M; q++) acc = fma(T1[IXM(i, q)], J[IXM(j, q)], acc);
-                return Pp[sidx(i, j)] - acc;
-            };
+            for (int i = 0; i < M; i++) {
+                double T1r[M];
 #pragma unroll
-            for (int j = 0; j < M; j++) {
+                for (int j = 0; j < M; j++) {
+                    double acc = J[IXM(i, 0)] * (first_step ? Dfull[IXM(0, j)] : Dsym[sidx(0, j)]);
 #pragma unroll
-                for (int i = 0; i < j; i++) Ps[sidx(i, j)] = (smooth(j, i) + smooth(i, j)) / 2.0;
-                const double dj = smooth(j, j);
-                Ps[sidx(j, j)] = (dj + dj) / 2.0;
+                    for (int q = 1; q < M; q++)
+                        acc = fma(J[IXM(i, q)], first_step ? Dfull[IXM(q, j)] : Dsym[sidx(q, j)], acc);
+                    T1r[j] = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < M; j++) {
+                    double acc = T1r[0] * J[IXM(j, 0)];
+#pragma unroll
+                    for (int q = 1; q < M; q++) acc = fma(T1r[q], J[IXM(j, q)], acc);
+                    F[IXM(i, j)] = cur.Pp[sidx(i, j)] - acc;
+                }
+#pragma unroll
+                for (int j = 0; j < i; j++) Ps[sidx(j, i)] = (F[IXM(i, j)] + F[IXM(j, i)]) / 2.0;
+                Ps[sidx(i, i)] = (F[IXM(i, i)] + F[IXM(i, i)]) / 2.0;
             }
         }
 #pragma unroll
         for (int i = 0; i < M; i++) Ss[i] = Sn[i];
-        store_vec<M>(a.S_SMOOTH, t, B, c, Ss);
-        store_sym<M>(a.P_SMOOTH, t, B, c, Ps);
-        if (a.u_opt_smooth) {
+#pragma unroll
+        for (int q = 0; q < kNpi; q++) u_pend[q] = cur.u[q];
+        if (a.u_opt_smooth) {                                  // :229
             double sn_unused[M];
-            nlin_state_update<M, FLIP>(p, a.mf, u_in, Ss, sn_unused);
-            store_u(a.u_opt_smooth, a, t, c, u_in);
+            nlin_state_update<M, FLIP>(p, a.mf, u_pend, Ss, sn_unused);
         }
-    }
+        t_pend = t;
+        rank_pend = rank;
+    };
+    if (T >= 2) step(T - 2, std::true_type{});
+    for (int k = T - 3; k >= 0; k--) step(k, std::false_type{});
+    flush();
     if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }

@@ -10,6 +10,7 @@
 // B/64 waves spread over the 1024 SIMDs of the chip as evenly as the batch allows.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "ekf_device.hpp"
@@ -45,6 +46,8 @@ struct KArgs {
     // generic models: word set by ekf_precheck when the batch must take the dense kernels (non-symmetric
     // Ps_init or non-diagonal Q_w); NULL = dense kernels always run (NewCase models)
     int *dense_flag;
+    // chain range [c0, c0 + cn) this launch covers (a call may be split into chunks on two streams)
+    int c0, cn;
 };
 
 // position in the caller's time axis of filter step k (flipped wrappers run the
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
     extern __shared__ double lds[];   // three sliding windows [3][L][64], one column per lane
     if (a.dense_flag && !*a.dense_flag) return;   // the symmetric fast path (ekf_fwd_sym) handles this batch
     const int lane = threadIdx.x;
-    const int c = blockIdx.x * kWave + lane;
-    if (c >= a.B) return;
+    const int c = a.c0 + blockIdx.x * kWave + lane;
+    if (c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
@@ -266,12 +269,12 @@ template <int M>
 __global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
 {
     const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)(a.T - 1) * a.B;
+    const size_t total = (size_t)(a.T - 1) * a.cn;
     if (item >= total) return;
     const int B = a.B;
     // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
-    const int t1 = a.pinv_pos0 + (int)(item / B);
-    const int c = (int)(item % B);
+    const int t1 = a.pinv_pos0 + (int)(item / a.cn);
+    const int c = a.c0 + (int)(item % a.cn);
     double P[M * M];
     // P_MINUS is stored symmetrised (:161): read the upper triangle only and mirror it
 #pragma unroll
@@ -305,8 +308,8 @@ template <int M, int FLIP, int GENERIC>
 __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 {
     if (a.dense_flag && !*a.dense_flag) return;   // eks_bwd_sym handles this batch
-    const int c = blockIdx.x * kWave + threadIdx.x;
-    if (c >= a.B) return;
+    const int c = a.c0 + blockIdx.x * kWave + threadIdx.x;
+    if (c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     ChainPrm p;
@@ -589,11 +592,79 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     return w;
 }
 
+// ---------------------------------------------------------------------------
+// launch logic
+// ---------------------------------------------------------------------------
+// The sequential kernels keep one chain per lane and (for m = 6) one wave per SIMD, so a batch whose wave
+// count is not a multiple of the chip's SIMD count leaves a tail round in which few SIMDs work, and while a
+// sequential kernel is latency-bound the rest of the chip idles.  A full call (phase 0) may therefore be split
+// into chunks of chains, each enqueued (forward -> pinv -> backward) on its own helper stream: the hardware
+// queues then interleave one chunk's (chain, step)-parallel eks_pinv grid with the other chunks' long-lived
+// sequential waves.  Chunks never share data, so stream order inside a chunk is the only dependency.
+constexpr int kMaxChunks = 16;
+struct SideStreams {
+    hipStream_t stream[kMaxChunks] = {};
+    hipEvent_t join[kMaxChunks] = {};
+    hipEvent_t fork = nullptr;
+    int n = 0, device = -1;
+};
+static thread_local SideStreams g_side;   // helper streams of the calling thread (created on first use)
+
+static hipError_t side_streams(int n, SideStreams **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (g_side.device != dev) { g_side = SideStreams(); g_side.device = dev; }
+    if (!g_side.fork && (e = hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming)) != hipSuccess) return e;
+    for (; g_side.n < n; g_side.n++) {
+        if ((e = hipStreamCreateWithFlags(&g_side.stream[g_side.n], hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&g_side.join[g_side.n], hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    *out = &g_side;
+    return hipSuccess;
+}
+
 // phase: 0 = everything; 1 = forward kernel; 2 = smoother (pinv + backward); 3 = pinv kernel; 4 = backward kernel
 template <int M, int FLIP, int GENERIC>
-static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, hipStream_t st)
+static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth, int hint, size_t shmem, hipStream_t st)
 {
-    const int blocks = (ka.B + kWave - 1) / kWave;
+    ka.c0 = c0; ka.cn = cn;
+    const int blocks = (cn + kWave - 1) / kWave;
+    const bool run_sym = GENERIC && hint != 2, run_dense = !GENERIC || hint != 1;
+    hipError_t e = hipSuccess;
+    if (phase == 0 || phase == 1) {
+        if (run_sym) {   // hint 0: both variants are enqueued, the one ekf_precheck did not select returns at once
+            hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (run_dense) {
+            hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+    }
+    if (!smooth) return e;
+    if (GENERIC && ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
+        const size_t items = (size_t)(ka.T - 1) * cn;
+        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ka);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (phase == 0 || phase == 2 || phase == 4) {
+        if (run_sym) {
+            hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (run_dense) {
+            hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
+            e = hipGetLastError();
+        }
+    }
+    return e;
+}
+
+template <int M, int FLIP, int GENERIC>
+static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint, int chunks, hipStream_t st)
+{
     const size_t shmem = (size_t)3 * ka.L * kWave * sizeof(double);
     hipError_t e = hipSuccess;
     if (phase == 0 || phase == 1) {
@@ -608,32 +679,59 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, hipStrea
             }
         }
         if (GENERIC) {
-            // fast path unless ekf_precheck finds a non-symmetric Ps_init / non-diagonal Q_w in the batch;
-            // both variants are enqueued, the one that is not selected returns at once
+            // hint 0: fast path unless ekf_precheck finds a non-symmetric Ps_init / non-diagonal Q_w in the batch;
+            // hint 1 / 2: the caller decided; the flag the kernels test is set accordingly
             if ((e = hipMemsetAsync(ka.dense_flag, 0, sizeof(int), st)) != hipSuccess) return e;
-            hipLaunchKernelGGL((ekf_precheck<M>), dim3((ka.B + 255) / 256), dim3(256), 0, st, ka, ka.dense_flag);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (hint == 0) {
+                hipLaunchKernelGGL((ekf_precheck<M>), dim3((ka.B + 255) / 256), dim3(256), 0, st, ka, ka.dense_flag, 0);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            } else if (hint == 2) {
+                hipLaunchKernelGGL((ekf_precheck<M>), dim3(1), dim3(64), 0, st, ka, ka.dense_flag, 1);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
         }
-        hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (!smooth) return e;
-    if (GENERIC && ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
-        const size_t items = (size_t)(ka.T - 1) * ka.B;
-        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ka);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    if (phase == 0 || phase == 2 || phase == 4) {
-        if (GENERIC) {
-            hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (phase == 0 && chunks == -1 && smooth) {
+        // "round + tail" split: the main chunk is a whole number of rounds of one wave per SIMD; the tail chunk's
+        // forward kernel starts when the main chunk's forward kernel has finished (so that it does not take
+        // SIMDs from it) and then runs beside the main chunk's eks_pinv grid
+        int dev = 0, cus = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        const int simds = cus * 4, waves = (ka.B + kWave - 1) / kWave;
+        const int main_chains = (waves / simds) * simds * kWave, tail_chains = ka.B - main_chains;
+        if (main_chains > 0 && tail_chains > 0) {
+            SideStreams *ss = nullptr;
+            if ((e = side_streams(1, &ss)) != hipSuccess) return e;
+            if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, 0, main_chains, 1, smooth, hint, shmem, st)) != hipSuccess) return e;
+            if ((e = hipEventRecord(ss->fork, st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(ss->stream[0], ss->fork, 0)) != hipSuccess) return e;
+            if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, main_chains, tail_chains, 0, smooth, hint, shmem, ss->stream[0])) != hipSuccess) return e;
+            if ((e = hipEventRecord(ss->join[0], ss->stream[0])) != hipSuccess) return e;
+            if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, 0, main_chains, 2, smooth, hint, shmem, st)) != hipSuccess) return e;
+            return hipStreamWaitEvent(st, ss->join[0], 0);
         }
-        hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
-        e = hipGetLastError();
+        return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
     }
-    return e;
+    if (phase != 0 || chunks <= 1 || ka.B < chunks * kWave)
+        return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
+    // chunked: fork the helper streams off the caller's stream, one chunk each, join back
+    SideStreams *ss = nullptr;
+    if ((e = side_streams(chunks, &ss)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ss->fork, st)) != hipSuccess) return e;
+    const int waves = (ka.B + kWave - 1) / kWave;
+    int c0 = 0;
+    for (int i = 0; i < chunks; i++) {
+        const int w = waves / chunks + (i < waves % chunks ? 1 : 0);      // whole waves per chunk
+        const int cn = (i == chunks - 1) ? ka.B - c0 : w * kWave;
+        if (cn <= 0) continue;
+        if ((e = hipStreamWaitEvent(ss->stream[i], ss->fork, 0)) != hipSuccess) return e;
+        if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, c0, cn, 0, smooth, hint, shmem, ss->stream[i])) != hipSuccess) return e;
+        if ((e = hipEventRecord(ss->join[i], ss->stream[i])) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, ss->join[i], 0)) != hipSuccess) return e;
+        c0 += cn;
+    }
+    return hipSuccess;
 }
 
 }  // namespace epi
@@ -681,6 +779,8 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     }
     // three fp64 windows of L samples per lane must fit the CU's 160 KiB LDS
     if (d->phase < 0 || d->phase > 4) { set_err(err, "phase must be 0..4"); return EPI_ERR_BAD_ARG; }
+    if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
+    if (d->chunks < -1) { set_err(err, "chunks must be >= -1"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
 }
@@ -754,15 +854,48 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     const bool smooth = (om & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && (om & EPI_OUT_U_OPT_SMOOTH)) ||
                         out->pinv_rank || out->status;
     hipStream_t st = (hipStream_t)stream;
+    int chunks = d->chunks;
+    if (chunks > kMaxChunks) chunks = kMaxChunks;
+    const int hint = mi.generic ? d->path_hint : 2;
     hipError_t e;
     switch (d->model) {
-    case EPI_MODEL_SIA3: e = launch_chain<3, 0, 1>(ka, d->phase, smooth, st); break;
-    case EPI_MODEL_SIA6: e = launch_chain<6, 0, 1>(ka, d->phase, smooth, st); break;
-    case EPI_MODEL_SIA3_BWD: e = launch_chain<3, 1, 1>(ka, d->phase, smooth, st); break;
-    case EPI_MODEL_SIA6_BWD: e = launch_chain<6, 1, 1>(ka, d->phase, smooth, st); break;
-    default: e = launch_chain<6, 0, 0>(ka, d->phase, smooth, st); break;
+    case EPI_MODEL_SIA3: e = launch_chain<3, 0, 1>(ka, d->phase, smooth, hint, chunks, st); break;
+    case EPI_MODEL_SIA6: e = launch_chain<6, 0, 1>(ka, d->phase, smooth, hint, chunks, st); break;
+    case EPI_MODEL_SIA3_BWD: e = launch_chain<3, 1, 1>(ka, d->phase, smooth, hint, chunks, st); break;
+    case EPI_MODEL_SIA6_BWD: e = launch_chain<6, 1, 1>(ka, d->phase, smooth, hint, chunks, st); break;
+    default: e = launch_chain<6, 0, 0>(ka, d->phase, smooth, hint, chunks, st); break;
     }
     if (e != hipSuccess) return hip_fail(err, e, "kernel launch");
+    return EPI_OK;
+}
+
+int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err)
+{
+    int rc = epi_ekf_validate(d, err);
+    if (rc != EPI_OK) return rc;
+    if (!in || !fast_ok || !in->Ps_init || !in->Ps_final || !in->Q) { set_err(err, "NULL argument"); return EPI_ERR_BAD_ARG; }
+    const ModelInfo &mi = MODEL_TABLE[d->model];
+    *fast_ok = 0;
+    if (!mi.generic) return EPI_OK;   // the NewCase models never symmetrise: dense kernels only
+    KArgs ka{};
+    ka.B = d->B;
+    ka.Ps_init = mi.flipped ? in->Ps_final : in->Ps_init;
+    ka.Q = in->Q;
+    int *flag = nullptr;
+    hipError_t e = hipMalloc((void **)&flag, sizeof(int));
+    if (e != hipSuccess) return hip_fail(err, e, "hipMalloc");
+    hipStream_t st = (hipStream_t)stream;
+    int host_flag = 1;
+    if ((e = hipMemsetAsync(flag, 0, sizeof(int), st)) == hipSuccess) {
+        if (mi.m == 3) hipLaunchKernelGGL((ekf_precheck<3>), dim3((d->B + 255) / 256), dim3(256), 0, st, ka, flag, 0);
+        else hipLaunchKernelGGL((ekf_precheck<6>), dim3((d->B + 255) / 256), dim3(256), 0, st, ka, flag, 0);
+        if ((e = hipGetLastError()) == hipSuccess)
+            e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(flag);
+    if (e != hipSuccess) return hip_fail(err, e, "precheck");
+    *fast_ok = host_flag ? 0 : 1;
     return EPI_OK;
 }
 

@@ -147,10 +147,13 @@ def _causal_ma(x, n):
 def _zero_lag_ma(x, n):
     """Forward-backward moving average (stands in for MATLAB filtfilt(ones(1,n), n, x);
     edge handling by odd reflection of 3*(n-1) samples like filtfilt)."""
-    pad = 3 * (n - 1)
-    lo = 2 * x[0] - x[pad:0:-1]
-    hi = 2 * x[-1] - x[-2:-pad - 2:-1]
-    y = np.concatenate([lo, x, hi], axis=0)
+    pad = min(3 * (n - 1), x.shape[0] - 1)
+    if pad > 0:
+        lo = 2 * x[0] - x[pad:0:-1]
+        hi = 2 * x[-1] - x[-2:-pad - 2:-1]
+        y = np.concatenate([lo, x, hi], axis=0)
+    else:
+        y = x
     y = _causal_ma(y, n)
     y = _causal_ma(y[::-1], n)[::-1]
     return y[pad:pad + x.shape[0]]

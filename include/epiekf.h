@@ -112,6 +112,16 @@ typedef struct epi_batch_desc {
     int32_t phase;        /* 0: forward EKF then backward EKS (one reference call).  For per-kernel timing a
                              caller may enqueue the stages one by one, in order, on the same buffers:
                              1 = forward kernel; 2 = smoother (3 then 4); 3 = pinv kernel; 4 = backward recursion */
+    int32_t path_hint;    /* kernels of the generic (symmetrising) models: 0 = decide on the device (both the
+                             symmetric-packed and the dense variant are enqueued, one returns at once);
+                             1 = epi_ekf_precheck_device() said the batch qualifies for the symmetric-packed
+                             kernels (Ps_init bit-wise symmetric, Q_w diagonal): enqueue only those;
+                             2 = dense kernels only */
+    int32_t chunks;       /* > 1: split the chains of a full call (phase 0) into this many chunks, each
+                             enqueued on its own helper stream, so that one chunk's (chain, step)-parallel
+                             eks_pinv grid fills the SIMDs the other chunks' one-wave-per-SIMD sequential
+                             kernels leave idle; 0/1: one chunk on the caller's stream; -1: "rounds + tail" (the
+                             waves beyond a whole number of one-wave-per-SIMD rounds form the second chunk) */
 } epi_batch_desc;
 
 typedef struct epi_inputs {
@@ -136,6 +146,8 @@ typedef struct epi_outputs {
 int epi_model_dim(int model);                                   /* 3, 6 or -1 */
 int epi_ekf_validate(const epi_batch_desc *d, char *err);       /* descriptor checks only, no GPU */
 size_t epi_ekf_workspace_bytes(const epi_batch_desc *d);        /* device scratch a run needs */
+/* Synchronous: inspects Ps_init / Q (device pointers) and reports in *fast_ok whether path_hint = 1 is valid. */
+int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err);
 
 /* All pointers in `in`/`out`/`workspace` are DEVICE pointers on the current HIP
  * device; `stream` is a hipStream_t (NULL = default stream).  Asynchronous:
