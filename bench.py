@@ -70,6 +70,24 @@ def make_workload(args, rank):
     return w, name
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic_summary.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of profiles/traffic_probe.py on this same
+    workload, corrected by the calibration copy as MI355X_MICROARCH.md prescribes).  None if the bench is not
+    running the profiled workload."""
+    if args.workload != "cfg4" or (args.regions, args.eps, args.t_hist, args.horizon, args.outputs) != (300, 250, 400, 120, "all"):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_summary.json")))
+    if not files:
+        return None
+    ks = json.load(open(files[-1]))["kernels"]
+    for name, v in ks.items():
+        if name.startswith(kernel):
+            return v["hbm_bytes"]
+    return None
+
+
 def cpu_baseline(w, args):
     """The CPU oracle (C restatement of Tools/*.m, MATLAB unavailable) timed on this host's cores over a
     bounded sample of the same workload: every k-th chain, all days, all outputs."""
@@ -179,7 +197,7 @@ def main():
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
                        "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args), "kernel": dom,
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes},
             "kernels": {**{k + "_ms": v for k, v in ms.items()},
                         **{k + "_GBs": alg[k] * steps_per_pass / (ms[k] * 1e-3) / 1e9 for k in ms},

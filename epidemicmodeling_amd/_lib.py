@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "libepiekf.so")
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_seirp_sim_device",
+    "epi_calib_copy_f64_device",
 ]
 
 
@@ -99,6 +100,8 @@ def lib():
         h.epi_seirp_sim_device.restype = C.c_int
         h.epi_seirp_sim_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+        h.epi_calib_copy_f64_device.restype = C.c_int
+        h.epi_calib_copy_f64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p]
         if h.epi_abi_version() != 1:
             raise ImportError("libepiekf.so ABI version mismatch")
         _lib = h

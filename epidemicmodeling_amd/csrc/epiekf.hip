@@ -556,6 +556,15 @@ __global__ __launch_bounds__(256) void seirp_sim(int B, int K, int par_steps, do
     }
 }
 
+// Measurement utility: streams n doubles src -> dst with the SAME access shape as the filter kernels (one
+// 8-byte element per lane, 512 B per wave instruction, grid-stride).  profiles/traffic_probe.py uses it to
+// calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on a known byte count (MI355X_MICROARCH.md, HBM section).
+__global__ __launch_bounds__(256) void calib_copy_f64(const double *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -953,6 +962,15 @@ int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_ou
     if (dout.pinv_rank && (e = hipMemcpy(out->pinv_rank, dout.pinv_rank, T * B * 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
     if (dout.status && (e = hipMemcpy(out->status, dout.status, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
     for (void *p : allocs) (void)hipFree(p);
+    return EPI_OK;
+}
+
+int epi_calib_copy_f64_device(const double *src, double *dst, size_t n, void *stream, char *err)
+{
+    if (!src || !dst || n == 0) { set_err(err, "bad calibration arguments"); return EPI_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(calib_copy_f64, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "calib_copy_f64 launch");
     return EPI_OK;
 }
 

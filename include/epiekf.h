@@ -196,6 +196,10 @@ int epi_seirp_sim_device(int32_t B, int32_t K, int32_t par_steps, double dt, int
                          int32_t integrator, const double *par, const double *init, const double *sat,
                          double *out, void *stream, char *err);
 
+/* Measurement utility (not part of the reference's interface): copies n doubles src -> dst with the filter
+ * kernels' access shape (8 B per lane); used to calibrate the HBM traffic counters on a known byte count. */
+int epi_calib_copy_f64_device(const double *src, double *dst, size_t n, void *stream, char *err);
+
 const char *epi_status_string(int status);
 int epi_abi_version(void);
 
