@@ -48,8 +48,11 @@ def parse():
     ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg3", "cfg5"])
     ap.add_argument("--outputs", default="all", choices=["all", "reduced"],
                     help="reduced = u_opt_smooth + S_SMOOTH only (what TrainPredictPrescribeNPI.m:460-493 consumes)")
-    ap.add_argument("--chunks", type=int, default=8,
-                    help="chain chunks a full call is split into (helper streams; DESIGN.md); 0/1 = single stream")
+    ap.add_argument("--chunks", type=int, default=-1,
+                    help="chain chunks a full call is split into (helper streams; DESIGN.md); 0/1 = single stream, "
+                         "-1 = whole one-wave-per-SIMD rounds + tail")
+    ap.add_argument("--no-score", action="store_true",
+                    help="skip the scenario-scoring tail (SIalpha_Controlled + NPICost on the horizon) after each pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chains", type=int, default=0, help="0 = sized for ~15 s")
     return ap.parse_args()
@@ -96,12 +99,15 @@ def cpu_baseline(w, args):
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     n = args.cpu_sample_chains
     if n <= 0:
-        # ~20 k steps/s/core for the 6-state filter+smoother, ~80 k for the 3-state one: aim at ~15 s
-        rate = (20e3 if w.m == 6 else 80e3) * cores
-        n = int(max(cores * 4, min(w.B, rate * 15.0 / w.T)))
+        # pilot run to size the sample for ~12 s of CPU work on this host (capped by the whole workload)
+        pilot = w.select(np.linspace(0, w.B - 1, min(w.B, cores * 64)).astype(np.int64))
+        H.oracle_batch(pilot.select(np.arange(min(pilot.B, cores))), n_threads=cores)     # warm the library / threads
+        t0 = time.perf_counter()
+        H.oracle_batch(pilot, n_threads=cores)
+        rate = pilot.B * pilot.T / (time.perf_counter() - t0)
+        n = int(max(cores * 4, min(w.B, rate * 12.0 / w.T)))
     idx = np.linspace(0, w.B - 1, n).astype(np.int64)
     ws = w.select(idx)
-    H.oracle_batch(w.select(idx[: max(cores, 8)]), n_threads=cores)     # warm the library / threads
     t0 = time.perf_counter()
     H.oracle_batch(ws, n_threads=cores)
     dt = time.perf_counter() - t0
@@ -136,6 +142,29 @@ def main():
     steps_per_pass = w.B * w.T
     t_hist_idx = w.meta.get("T_hist", w.T) - 1
 
+    # scenario-scoring tail of the sweep (TrainPredictPrescribeNPI.m:481-493): per-chain (J0, J1) are what leaves
+    # the GPU at the end of a pass; with N > 1 they are gathered to rank 0 (the path's only collective)
+    score = (not args.no_score) and args.workload == "cfg4" and "u_opt_smooth" in runner.out
+    score_state = {}
+
+    def prepare_scoring():
+        from epidemicmodeling_amd import layout as L_
+        n, Bc = w.n_npi, w.B
+        sp = torch.zeros((batch.SIM_PRM_COUNT, Bc), dtype=torch.float64, device=dev)
+        prm = dw.prm
+        sp[3], sp[4], sp[5] = prm[L_.PRM_ALPHA_MIN], prm[L_.PRM_ALPHA_MAX], prm[L_.PRM_GAMMA]
+        sp[6], sp[7], sp[11] = prm[L_.PRM_B], prm[L_.PRM_BETA], 1.0
+        sp[batch.SIM_A:batch.SIM_A + n] = prm[L_.PRM_A:L_.PRM_A + n]
+        sp[batch.SIM_U_MAX:batch.SIM_U_MAX + n] = prm[L_.PRM_U_MAX:L_.PRM_U_MAX + n]
+        sp[batch.SIM_W:batch.SIM_W + n] = 1.0                       # npi_weights = ones (testPrescribeXPRIZE02.m:56)
+        S = runner.out["S_SMOOTH"]
+        th = t_hist_idx + 1
+        # historic prefixes are inputs of the scoring step (in the reference they come from the 3-state run of the
+        # region); computed once, outside the timed region
+        score_state["J0p"] = (S[:th, 0] * S[:th, 1] * S[:th, 2]).sum(dim=0)
+        score_state["J1p"] = runner.out["u_opt_smooth"][:th].sum(dim=(0, 1))
+        score_state["sp"] = sp
+
     def one_step(events=None):
         if events is None:
             runner.run()                      # the call a user makes: forward + pinv + backward
@@ -143,10 +172,20 @@ def main():
             e0, e1, e2, e3 = events
             e0.record(); runner.run(phase=1); e1.record(); runner.run(phase=3); e2.record()
             runner.run(phase=4); e3.record()
-        if world > 1:
-            # end-of-sweep result gather (per-chain smoothed state at the last observed day) to rank 0
+        if score and score_state:
+            sp = score_state["sp"]
+            sp[0:3].copy_(runner.out["S_SMOOTH"][t_hist_idx, 0:3])
+            sc = batch.score_sweep(runner.out["u_opt_smooth"], t_hist_idx + 1, sp, score_state["J0p"], score_state["J1p"])
+            if world > 1:
+                batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
+        elif world > 1:
+            # no scoring: gather the per-chain smoothed state at the last observed day to rank 0
             batch.gather_to_root(runner.out["S_SMOOTH"][t_hist_idx].contiguous())
 
+    one_step()
+    torch.cuda.synchronize(dev)
+    if score:
+        prepare_scoring()
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
@@ -195,7 +234,8 @@ def main():
             "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "chunks": args.chunks,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
-                       "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather to rank 0"},
+                       "scoring_tail": bool(score),
+                       "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather of (J0, J1) to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args), "kernel": dom,
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes},

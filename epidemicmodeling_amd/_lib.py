@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libepiekf.so")
 
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
-    "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_seirp_sim_device",
+    "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_calib_copy_f64_device",
 ]
 
@@ -46,7 +46,7 @@ class Outputs(C.Structure):
 
 
 class SimDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("abi_version", "B", "K", "Su", "n_npi", "noise", "with_cost", "reserved")]
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "B", "K", "Su", "n_npi", "noise", "with_cost", "prefix_days")]
 
 
 _lib = None
@@ -97,6 +97,8 @@ def lib():
                                        C.c_char_p]
         h.epi_sialpha_sim_device.restype = C.c_int
         h.epi_sialpha_sim_device.argtypes = [C.POINTER(SimDesc)] + [C.c_void_p] * 9 + [C.c_void_p, C.c_char_p]
+        h.epi_sialpha_score_device.restype = C.c_int
+        h.epi_sialpha_score_device.argtypes = [C.POINTER(SimDesc)] + [C.c_void_p] * 11 + [C.c_void_p, C.c_char_p]
         h.epi_seirp_sim_device.restype = C.c_int
         h.epi_seirp_sim_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]

@@ -173,7 +173,7 @@ def sialpha_sim(u, sp, z=None, u_series=None, with_cost=False, store=True, devic
     B = sp.shape[1]
     d = _lib.SimDesc()
     d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, B, K, Su, n_npi
-    d.noise, d.with_cost, d.reserved = int(z is not None), int(with_cost), 0
+    d.noise, d.with_cost, d.prefix_days = int(z is not None), int(with_cost), 0
     out = {}
     if store:
         for n in ("s", "i", "alpha"):
@@ -203,5 +203,34 @@ def seirp_sim(par, init, dt, K, sat=None, integrator="euler", device="cuda:0"):
     rc = _lib.lib().epi_seirp_sim_device(B, K, par.shape[0], float(dt), int(sat is not None),
                                          {"euler": 0, "rk4": 1}[integrator], _ptr(par), _ptr(init), _ptr(sat),
                                          _ptr(out), C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return out
+
+
+def score_sweep(u_opt_smooth, t_hist, sp, J0_prefix, J1_prefix, store=False):
+    """Scenario scoring tail of the Pareto sweep (Tools/TrainPredictPrescribeNPI.m:481-493) on the device.
+
+    u_opt_smooth : torch [T, n_npi, B] (the smoother's output, left in HBM); its last T - t_hist days drive
+                   SIalpha_Controlled from the end-of-history state given in `sp` (SIM_* rows, [48, B]);
+    J0_prefix/J1_prefix : [B] sequential sums over the t_hist historic days (newcases; weights.*inputs).
+    Returns dict with J0, J1 [B] (NPICost over the whole span) and, if store, the simulated s, i, alpha [H, B]."""
+    dev = u_opt_smooth.device
+    T, n_npi, B = u_opt_smooth.shape
+    H = T - t_hist
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev) if not isinstance(a, torch.Tensor) else a
+    sp, J0p, J1p = t(sp), t(J0_prefix), t(J1_prefix)
+    u_h = u_opt_smooth[t_hist:]                 # contiguous view: [H, n_npi, B]
+    d = _lib.SimDesc()
+    d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, B, H, B, n_npi
+    d.noise, d.with_cost, d.prefix_days = 0, 1, int(t_hist)
+    out = {"J0": torch.empty((B,), dtype=torch.float64, device=dev), "J1": torch.empty((B,), dtype=torch.float64, device=dev)}
+    if store:
+        for n in ("s", "i", "alpha"):
+            out[n] = torch.empty((H, B), dtype=torch.float64, device=dev)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_sialpha_score_device(C.byref(d), None, _ptr(u_h), _ptr(sp), None, _ptr(J0p), _ptr(J1p),
+                                             _ptr(out.get("s")), _ptr(out.get("i")), _ptr(out.get("alpha")),
+                                             _ptr(out["J0"]), _ptr(out["J1"]), C.c_void_p(st.cuda_stream), err)
     _lib.check(rc, err)
     return out

@@ -444,7 +444,9 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
                                                    const double *__restrict__ u, const double *__restrict__ sp,
                                                    const double *__restrict__ z, double *__restrict__ so,
                                                    double *__restrict__ io, double *__restrict__ ao,
-                                                   double *__restrict__ J0, double *__restrict__ J1)
+                                                   double *__restrict__ J0, double *__restrict__ J1,
+                                                   const double *__restrict__ J0_prefix,
+                                                   const double *__restrict__ J1_prefix)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.B) return;
@@ -458,7 +460,10 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
     double ga[kNpi], um[kNpi], w[kNpi];
 #pragma unroll
     for (int k = 0; k < kNpi; k++) { ga[k] = gamma * g(EPI_SIM_A + k); um[k] = g(EPI_SIM_U_MAX + k); w[k] = g(EPI_SIM_W + k); }
-    double acc0 = 0.0, acc1 = 0.0;
+    // NPICost over [historic days, simulated days] (TrainPredictPrescribeNPI.m:481-493): the historic part of
+    // the two sequential sums arrives as a per-chain prefix and the simulated days are added in order
+    const bool pre = (d.prefix_days > 0) && J0_prefix && J1_prefix;
+    double acc0 = pre ? J0_prefix[c] : 0.0, acc1 = pre ? J1_prefix[c] : 0.0;
     for (int t = 0; t < d.K; t++) {
         double uk[kNpi];
 #pragma unroll
@@ -479,19 +484,20 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
         if (ao) ao[(size_t)t * B + c] = al;
         if (d.with_cost) {
             const double nc = s * i * al;
-            acc0 = (t == 0) ? nc : acc0 + nc;
+            acc0 = (t == 0 && !pre) ? nc : acc0 + nc;
             // mean(weights(:).*inputs(:)) in column-major order: NPI index fastest
 #pragma unroll
             for (int k = 0; k < kNpi; k++)
                 if (k < d.n_npi) {
                     const double term = w[k] * uk[k];
-                    acc1 = (t == 0 && k == 0) ? term : acc1 + term;
+                    acc1 = (t == 0 && k == 0 && !pre) ? term : acc1 + term;
                 }
         }
     }
     if (d.with_cost) {
-        if (J0) J0[c] = acc0 / (double)d.K;
-        if (J1) J1[c] = acc1 / (double)((size_t)d.n_npi * (size_t)d.K);
+        const size_t days = (size_t)d.K + (size_t)(pre ? d.prefix_days : 0);
+        if (J0) J0[c] = acc0 / (double)days;
+        if (J1) J1[c] = acc1 / (double)((size_t)d.n_npi * days);
     }
 }
 
@@ -974,19 +980,36 @@ int epi_calib_copy_f64_device(const double *src, double *dst, size_t n, void *st
     return EPI_OK;
 }
 
+static int sialpha_launch(const epi_sim_desc *d, const int32_t *u_series, const double *u, const double *sp,
+                          const double *z, double *s, double *i, double *alpha, double *J0, double *J1,
+                          const double *J0_prefix, const double *J1_prefix, void *stream, char *err)
+{
+    if (!d || d->abi_version != EPIEKF_ABI_VERSION || d->B < 1 || d->K < 1 || d->Su < 1 || d->n_npi < 1 ||
+        d->n_npi > EPI_MAX_NPI || !u || !sp || (d->noise && !z) || (!u_series && d->Su != d->B) || d->prefix_days < 0 ||
+        (d->prefix_days > 0 && (!J0_prefix || !J1_prefix))) {
+        set_err(err, "bad simulator descriptor"); return EPI_ERR_BAD_ARG;
+    }
+    const int blocks = (d->B + 255) / 256;
+    hipLaunchKernelGGL(sialpha_sim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, u_series, u, sp, z, s, i, alpha,
+                       J0, J1, J0_prefix, J1_prefix);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "sialpha_sim launch");
+    return EPI_OK;
+}
+
 int epi_sialpha_sim_device(const epi_sim_desc *d, const int32_t *u_series, const double *u, const double *sp,
                            const double *z, double *s, double *i, double *alpha, double *J0, double *J1,
                            void *stream, char *err)
 {
-    if (!d || d->abi_version != EPIEKF_ABI_VERSION || d->B < 1 || d->K < 1 || d->Su < 1 || d->n_npi < 1 ||
-        d->n_npi > EPI_MAX_NPI || !u || !sp || (d->noise && !z) || (!u_series && d->Su != d->B)) {
-        set_err(err, "bad simulator descriptor"); return EPI_ERR_BAD_ARG;
-    }
-    const int blocks = (d->B + 255) / 256;
-    hipLaunchKernelGGL(sialpha_sim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, u_series, u, sp, z, s, i, alpha, J0, J1);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(err, e, "sialpha_sim launch");
-    return EPI_OK;
+    if (d && d->prefix_days != 0) { set_err(err, "prefix_days needs epi_sialpha_score_device"); return EPI_ERR_BAD_ARG; }
+    return sialpha_launch(d, u_series, u, sp, z, s, i, alpha, J0, J1, nullptr, nullptr, stream, err);
+}
+
+int epi_sialpha_score_device(const epi_sim_desc *d, const int32_t *u_series, const double *u, const double *sp,
+                             const double *z, const double *J0_prefix, const double *J1_prefix, double *s, double *i,
+                             double *alpha, double *J0, double *J1, void *stream, char *err)
+{
+    return sialpha_launch(d, u_series, u, sp, z, s, i, alpha, J0, J1, J0_prefix, J1_prefix, stream, err);
 }
 
 int epi_seirp_sim_device(int32_t B, int32_t K, int32_t par_steps, double dt, int32_t saturated, int32_t integrator,

@@ -169,7 +169,7 @@ typedef struct epi_sim_desc {
     int32_t n_npi;
     int32_t noise;    /* 0: noise-free; 1: z given [K][3][B] standard normal draws */
     int32_t with_cost;/* 1: also J0/J1 of NPICost over the simulated span */
-    int32_t reserved;
+    int32_t prefix_days; /* epi_sialpha_score_device: days already summed into J0_prefix / J1_prefix */
 } epi_sim_desc;
 
 /* SIalpha_Controlled.m:1-32 batched.  sp [EPI_SIM_PRM_COUNT][B]; u [K][n_npi][Su];
@@ -186,6 +186,15 @@ enum {
 int epi_sialpha_sim_device(const epi_sim_desc *d, const int32_t *u_series, const double *u,
                            const double *sp, const double *z, double *s, double *i, double *alpha,
                            double *J0, double *J1, void *stream, char *err);
+
+/* Scenario scoring of the Pareto sweep (Tools/TrainPredictPrescribeNPI.m:481-493): simulate the horizon under the
+ * smoothed optimal control from the end-of-history state and return NPICost over [historic days, horizon days].
+ * J0_prefix[B] / J1_prefix[B] hold the sequential sums over the `prefix_days` historic days of
+ * s.*i.*alpha and of weights(:).*inputs(:) (column-major order); the kernel continues both sums in order, so
+ * J0 = mean([newcases_hist, newcases_sim]) and J1 = mean(weights.*[u_hist, u_sim]) exactly as NPICost.m:6-10. */
+int epi_sialpha_score_device(const epi_sim_desc *d, const int32_t *u_series, const double *u, const double *sp,
+                             const double *z, const double *J0_prefix, const double *J1_prefix, double *s, double *i,
+                             double *alpha, double *J0, double *J1, void *stream, char *err);
 
 /* SEIRP.m:1-32 / SEIRPSaturatedResource.m:1-38 batched: par [K][7][B] per-step parameter arrays in the
  * order alpha_e, alpha_i, kappa, rho, beta, mu, gamma (or constant-in-time: par [1][7][B], par_steps=1);
