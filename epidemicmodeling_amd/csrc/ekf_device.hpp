@@ -111,6 +111,27 @@ EPI_DEV void load_prm(ChainPrm &p, const double *__restrict__ prm, int B, int c,
     }
 }
 
+// ---- sliding windows of the innovation monitor (GenericEKF.m:172-179) -------
+// `win` is this lane's column of an LDS ring buffer (stride kWave doubles); the newest sample sits at `head`
+// and has already been written.  Returns the sum newest -> oldest, added strictly in that order (the
+// reference's cat/sum order).  The LDS reads are issued ten at a time so that their latencies overlap; only
+// the additions are serial.
+EPI_DEV double ring_sum(const double *win, int head, int L, double newest)
+{
+    constexpr int BLK = 10;
+    double sum = newest;
+    int idx = head, j = 1;
+    for (; j + BLK <= L; j += BLK) {
+        double v[BLK];
+#pragma unroll
+        for (int q = 0; q < BLK; q++) { idx = (idx + 1 == L) ? 0 : idx + 1; v[q] = win[idx * kWave]; }
+#pragma unroll
+        for (int q = 0; q < BLK; q++) sum = sum + v[q];
+    }
+    for (; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sum = sum + win[idx * kWave]; }
+    return sum;
+}
+
 // ---- dense helpers -------------------------------------------------------
 template <int M>
 EPI_DEV void mat_mul(const double (&A)[M * M], const double (&B)[M * M], double (&C)[M * M])

@@ -34,18 +34,22 @@ template <int M>
 EPI_DEV void store_sym(double *__restrict__ dst, int t, int B, int c, const double (&P)[nsym<M>()])
 {
     if (!dst) return;
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
+    const rsrc_t r = mk_rsrc(dst + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
-        for (int i = 0; i < M; i++) dst[((size_t)t * (M * M) + IXM(i, j)) * B + c] = P[sidx(i, j)];
+        for (int i = 0; i < M; i++) bst(r, voff, (unsigned)IXM(i, j) * rowb, P[sidx(i, j)]);
 }
 template <int M>
 EPI_DEV void load_sym(const double *__restrict__ src, int t, int B, int c, double (&P)[nsym<M>()])
 {
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
+    const rsrc_t r = mk_rsrc(src + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) P[sidx(i, j)] = src[((size_t)t * (M * M) + IXM(i, j)) * B + c];
+        for (int i = 0; i <= j; i++) P[sidx(i, j)] = bld(r, voff, (unsigned)IXM(i, j) * rowb);
 }
 
 // ---------------------------------------------------------------------------
@@ -90,8 +94,8 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     if (*dense_flag) return;          // ekf_fwd (dense) runs instead
     constexpr int NS = nsym<M>();
     const int lane = threadIdx.x;
-    const int c = a.c0 + blockIdx.x * kWave + lane;
-    if (c >= a.c0 + a.cn) return;
+    const int c = a.c0 + blockIdx.x * a.lw + lane;
+    if (lane >= a.lw || c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
@@ -123,8 +127,9 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     // Software pipeline of the inputs.  Vector-memory operations retire in issue order (one vmcnt), so a
     // load issued after a step's ~100 stores would wait for all of them to drain; the inputs of step k+1 are
     // therefore requested at the top of step k, ahead of its stores, and consumed one iteration later.
-    double x_nxt = a.x[(size_t)tpos<FLIP>(0, T) * a.Sx + sx];
-    double r_nxt = fixed_R ? 0.0 : a.R_series[sx];
+    const unsigned voff = (unsigned)c * 8u, voff_x = (unsigned)sx * 8u;
+    double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(0, T) * a.Sx, voff_x);
+    double r_nxt = fixed_R ? 0.0 : ldg(a.R_series, voff_x);
     double u_nxt[kNpi];
     load_u(a, tpos<FLIP>(0, T), su, u_nxt);
 
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         for (int q = 0; q < kNpi; q++) u_in[q] = u_nxt[q];
         if (k + 1 < T) {
             const int tn = tpos<FLIP>(k + 1, T);
-            x_nxt = a.x[(size_t)tn * a.Sx + sx];
-            if (!fixed_R) r_nxt = a.R_series[(size_t)(k + 1) * a.Sx + sx];
+            x_nxt = ldg(a.x + (size_t)tn * a.Sx, voff_x);
+            if (!fixed_R) r_nxt = ldg(a.R_series + (size_t)(k + 1) * a.Sx, voff_x);
             load_u(a, tn, su, u_nxt);
         }
 
@@ -259,33 +264,23 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         store_vec<M>(a.S_PLUS, t, B, c, sk_plus);
         store_sym<M>(a.P_PLUS, t, B, c, Pp);
         store_vec<M>(a.K_GAIN, t, B, c, K);
-        if (a.innovations) a.innovations[(size_t)t * B + c] = innov;
+        if (a.innovations) stg(a.innovations + (size_t)t * B, voff, innov);
 
         // innovation monitor (identical to ekf_fwd)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
         head = (head == 0) ? (L - 1) : (head - 1);
         winMean[head * kWave] = innov;
-        double sum = innov;
-        {
-            int idx = head;
-            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sum = sum + winMean[idx * kWave]; }
-        }
+        const double sum = ring_sum(winMean, head, L, innov);
         const double mu = sum / (double)cnt;
         const double cc = (innov - mu) * (innov - mu);
         const double ccn = cc / (Rk + kEps);
         winCov[head * kWave] = cc;
         winCovN[head * kWave] = ccn;
-        double sumN = ccn;
-        {
-            int idx = head;
-            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumN = sumN + winCovN[idx * kWave]; }
-        }
-        if (a.rho) a.rho[(size_t)t * B + c] = sumN / (double)cnt;
+        const double sumN = ring_sum(winCovN, head, L, ccn);
+        if (a.rho) stg(a.rho + (size_t)t * B, voff, sumN / (double)cnt);
         if (fixed_R) {
             if (beta != 1.0 && valid && k < T - 1) {
-                double sumC = cc;
-                int idx = head;
-                for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumC = sumC + winCov[idx * kWave]; }
+                const double sumC = ring_sum(winCov, head, L, cc);
                 R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);
             } else {
                 R_next = R_v;
@@ -309,8 +304,8 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     if (*dense_flag) return;
     constexpr int NS = nsym<M>();
     const int lane = threadIdx.x;
-    const int c = a.c0 + blockIdx.x * kWave + lane;
-    if (c >= a.c0 + a.cn) return;
+    const int c = a.c0 + blockIdx.x * a.lw + lane;
+    if (lane >= a.lw || c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     LitePrm<VecLds> p;
@@ -362,7 +357,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         load_vec<M>(a.S_PLUS, t, B, c, d.Sp);
         load_sym<M>(a.P_PLUS, t, B, c, d.Pp);
         load_u(a, t, su, d.u);
-        d.rk = a.rankbuf[(size_t)t1 * B + c];
+        d.rk = ldg_i(a.rankbuf + (size_t)t1 * B, (unsigned)c * 4u);
         load_mat<M>(a.X, t1, B, c, d.X);          // unused garbage where the :211 guard fired (rk < 0)
         load_vec<M>(a.S_MINUS, t1, B, c, d.Sm1);
         load_sym<M>(a.P_MINUS, t1, B, c, d.Pm1);
@@ -373,7 +368,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     for (int q = 0; q < kNpi; q++) u_pend[q] = 0.0;
     auto flush = [&]() {          // store the previous step's results (Ss, Ps still hold them)
         if (t_pend < 0) return;
-        if (a.pinv_rank) a.pinv_rank[(size_t)t_pend * B + c] = rank_pend;
+        if (a.pinv_rank) stg_i(a.pinv_rank + (size_t)t_pend * B, (unsigned)c * 4u, rank_pend);
         store_vec<M>(a.S_SMOOTH, t_pend, B, c, Ss);
         store_sym<M>(a.P_SMOOTH, t_pend, B, c, Ps);
         if (a.u_opt_smooth) store_u(a.u_opt_smooth, a, t_pend, c, u_pend);

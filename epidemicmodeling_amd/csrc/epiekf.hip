@@ -48,50 +48,93 @@ struct KArgs {
     int *dense_flag;
     // chain range [c0, c0 + cn) this launch covers (a call may be split into chunks on two streams)
     int c0, cn;
+    // lanes used per 64-thread workgroup (<= 64).  When the batch needs more than one round of resident waves,
+    // the host narrows the waves so that the rounds are equally full (launch_chain): the sequential kernels are
+    // bound by HBM / per-CU memory throughput, which scales with active lanes, not by wave count.
+    int lw;
 };
 
 // position in the caller's time axis of filter step k (flipped wrappers run the
 // generic filter on time-reversed u/x and reverse every output: Backward*.m:19-40)
 template <int FLIP> EPI_DEV int tpos(int k, int T) { return FLIP ? (T - 1 - k) : k; }
 
+// Addressing.  Every array is [T][rows][B] (chain-minor), so an access is
+//     slice base (wave-uniform: kernel argument + uniform time index)  +  row * B * 8 (uniform)  +  8 * chain (per lane).
+// The per-step slice of an array is addressed through a buffer resource descriptor held in SGPRs
+// (cdna_hip_programming.md T8/T20): `buffer_load/store_dwordx2 v_data, v_off, s[rsrc], s_rowoff offen` with ONE shared
+// 32-bit per-lane byte offset, the row offset in an SGPR and hardware bounds checking -- no 64-bit per-lane address
+// arithmetic and no VGPR pairs per access.  A slice must stay below 4 GiB: rows * B * 8 < 2^32  =>  B <= 2^23.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+EPI_DEV rsrc_t mk_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, /*stride*/ 0, bytes, 0x00020000);
+}
+EPI_DEV double bld(rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+EPI_DEV void bst(rsrc_t r, unsigned voff, unsigned soff, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+EPI_DEV double ldg(const double *__restrict__ row, unsigned voff)
+{
+    return *(const double *)((const char *)row + voff);
+}
+EPI_DEV void stg(double *__restrict__ row, unsigned voff, double v) { *(double *)((char *)row + voff) = v; }
+EPI_DEV int ldg_i(const int32_t *__restrict__ row, unsigned voff4) { return *(const int32_t *)((const char *)row + voff4); }
+EPI_DEV void stg_i(int32_t *__restrict__ row, unsigned voff4, int v) { *(int32_t *)((char *)row + voff4) = v; }
+
 template <int M>
 EPI_DEV void store_vec(double *__restrict__ dst, int t, int B, int c, const double (&v)[M])
 {
     if (!dst) return;
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
+    const rsrc_t r = mk_rsrc(dst + (size_t)t * M * B, (unsigned)M * rowb);
 #pragma unroll
-    for (int i = 0; i < M; i++) dst[((size_t)t * M + i) * B + c] = v[i];
+    for (int i = 0; i < M; i++) bst(r, voff, (unsigned)i * rowb, v[i]);
 }
 template <int M>
 EPI_DEV void store_mat(double *__restrict__ dst, int t, int B, int c, const double (&P)[M * M])
 {
     if (!dst) return;
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
+    const rsrc_t r = mk_rsrc(dst + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
 #pragma unroll
-    for (int e = 0; e < M * M; e++) dst[((size_t)t * (M * M) + e) * B + c] = P[e];
+    for (int e = 0; e < M * M; e++) bst(r, voff, (unsigned)e * rowb, P[e]);
 }
 template <int M>
 EPI_DEV void load_vec(const double *__restrict__ src, int t, int B, int c, double (&v)[M])
 {
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
+    const rsrc_t r = mk_rsrc(src + (size_t)t * M * B, (unsigned)M * rowb);
 #pragma unroll
-    for (int i = 0; i < M; i++) v[i] = src[((size_t)t * M + i) * B + c];
+    for (int i = 0; i < M; i++) v[i] = bld(r, voff, (unsigned)i * rowb);
 }
 template <int M>
 EPI_DEV void load_mat(const double *__restrict__ src, int t, int B, int c, double (&P)[M * M])
 {
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
+    const rsrc_t r = mk_rsrc(src + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
 #pragma unroll
-    for (int e = 0; e < M * M; e++) P[e] = src[((size_t)t * (M * M) + e) * B + c];
+    for (int e = 0; e < M * M; e++) P[e] = bld(r, voff, (unsigned)e * rowb);
 }
 EPI_DEV void load_u(const KArgs &a, int t, int su, double (&u)[kNpi])
 {
+    const unsigned voff = (unsigned)su * 8u, rowb = (unsigned)a.Su * 8u;
+    const rsrc_t r = mk_rsrc(a.u + (size_t)t * a.n_npi * a.Su, (unsigned)a.n_npi * rowb);
 #pragma unroll
-    for (int k = 0; k < kNpi; k++)
-        u[k] = (k < a.n_npi) ? a.u[((size_t)t * a.n_npi + k) * a.Su + su] : 0.0;
+    for (int k = 0; k < kNpi; k++) u[k] = (k < a.n_npi) ? bld(r, voff, (unsigned)k * rowb) : 0.0;
 }
 EPI_DEV void store_u(double *__restrict__ dst, const KArgs &a, int t, int c, const double (&u)[kNpi])
 {
     if (!dst) return;
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)a.B * 8u;
+    const rsrc_t r = mk_rsrc(dst + (size_t)t * a.n_npi * a.B, (unsigned)a.n_npi * rowb);
 #pragma unroll
     for (int k = 0; k < kNpi; k++)
-        if (k < a.n_npi) dst[((size_t)t * a.n_npi + k) * a.B + c] = u[k];
+        if (k < a.n_npi) bst(r, voff, (unsigned)k * rowb, u[k]);
 }
 
 // ---------------------------------------------------------------------------
@@ -103,8 +146,8 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
     extern __shared__ double lds[];   // three sliding windows [3][L][64], one column per lane
     if (a.dense_flag && !*a.dense_flag) return;   // the symmetric fast path (ekf_fwd_sym) handles this batch
     const int lane = threadIdx.x;
-    const int c = a.c0 + blockIdx.x * kWave + lane;
-    if (c >= a.c0 + a.cn) return;
+    const int c = a.c0 + blockIdx.x * a.lw + lane;
+    if (lane >= a.lw || c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
@@ -227,28 +270,18 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
         head = (head == 0) ? (L - 1) : (head - 1);
         winMean[head * kWave] = innov;
-        double sum = innov;
-        {
-            int idx = head;
-            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sum = sum + winMean[idx * kWave]; }
-        }
+        const double sum = ring_sum(winMean, head, L, innov);
         const double mu = sum / (double)cnt;
         const double cc = (innov - mu) * (innov - mu);
         const double ccn = GENERIC ? cc / (Rk + kEps) : cc / Rk;
         winCov[head * kWave] = cc;
         winCovN[head * kWave] = ccn;
-        double sumN = ccn;
-        {
-            int idx = head;
-            for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumN = sumN + winCovN[idx * kWave]; }
-        }
+        const double sumN = ring_sum(winCovN, head, L, ccn);
         if (a.rho) a.rho[(size_t)t * B + c] = sumN / (double)cnt;
         if (fixed_R) {
             const bool adapt = GENERIC ? (beta != 1.0 && valid && k < T - 1) : (beta != 1.0 && valid);
             if (adapt) {
-                double sumC = cc;
-                int idx = head;
-                for (int j = 1; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sumC = sumC + winCov[idx * kWave]; }
+                const double sumC = ring_sum(winCov, head, L, cc);
                 if (GENERIC) R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);   // :184
                 else R_next = beta * Rk + (1.0 - beta) * sumC / (double)cnt;             // NewCase...m:111
             } else if (GENERIC) {
@@ -268,37 +301,43 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 template <int M>
 __global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
 {
-    const size_t item = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)(a.T - 1) * a.cn;
-    if (item >= total) return;
+    // grid: x = 256-chain tiles of the chain range, y = step; a workgroup shares one step => uniform row bases
+    const int cl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cl >= a.cn) return;
     const int B = a.B;
     // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
-    const int t1 = a.pinv_pos0 + (int)(item / a.cn);
-    const int c = a.c0 + (int)(item % a.cn);
+    const int t1 = a.pinv_pos0 + (int)blockIdx.y;
+    const int c = a.c0 + cl;
+    const unsigned voff = (unsigned)c * 8u;
     double P[M * M];
     // P_MINUS is stored symmetrised (:161): read the upper triangle only and mirror it
+    {
+        const unsigned rowb = (unsigned)B * 8u;
+        const rsrc_t r = mk_rsrc(a.P_MINUS + (size_t)t1 * (M * M) * B, (unsigned)(M * M) * rowb);
 #pragma unroll
-    for (int j = 0; j < M; j++)
+        for (int j = 0; j < M; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) {
-            const double v = a.P_MINUS[((size_t)t1 * (M * M) + IXM(i, j)) * B + c];
-            P[IXM(i, j)] = v;
-            P[IXM(j, i)] = v;
-        }
+            for (int i = 0; i <= j; i++) {
+                const double v = bld(r, voff, (unsigned)IXM(i, j) * rowb);
+                P[IXM(i, j)] = v;
+                P[IXM(j, i)] = v;
+            }
+    }
     bool bad = false;                                      // :211
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
         for (int i = 0; i <= j; i++) bad = bad || is_nonfinite(P[IXM(i, j)]);
+    int32_t *rrow = a.rankbuf + (size_t)t1 * B;
     if (bad) {
-        a.rankbuf[(size_t)t1 * B + c] = -1;
+        stg_i(rrow, (unsigned)c * 4u, -1);
         return;
     }
     double X[M * M];
     bool capped;
     const int rank = sym_pinv<M>(P, X, &capped);           // :215
     store_mat<M>(a.X, t1, B, c, X);
-    a.rankbuf[(size_t)t1 * B + c] = rank | (capped ? 0x100 : 0);
+    stg_i(rrow, (unsigned)c * 4u, rank | (capped ? 0x100 : 0));
 }
 
 // ---------------------------------------------------------------------------
@@ -308,8 +347,8 @@ template <int M, int FLIP, int GENERIC>
 __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 {
     if (a.dense_flag && !*a.dense_flag) return;   // eks_bwd_sym handles this batch
-    const int c = a.c0 + blockIdx.x * kWave + threadIdx.x;
-    if (c >= a.c0 + a.cn) return;
+    const int c = a.c0 + blockIdx.x * a.lw + threadIdx.x;
+    if ((int)threadIdx.x >= a.lw || c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     ChainPrm p;
@@ -378,7 +417,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
             mat_mul_bt<M>(Pp, A, PAt);                         // P_PLUS * A'
             if (GENERIC) {
                 // pinv(P_MINUS(:,:,k+1)) was computed by eks_pinv (one lane per (chain, step) pair)
-                const int rk = a.rankbuf[(size_t)t1 * B + c];
+                const int rk = ldg_i(a.rankbuf + (size_t)t1 * B, (unsigned)c * 4u);
                 if (rk < 0) {                                  // non-finite P_MINUS guard :211-213
 #pragma unroll
                     for (int e = 0; e < M * M; e++) J[e] = 0.0;
@@ -640,12 +679,40 @@ static hipError_t side_streams(int n, SideStreams **out)
     return hipSuccess;
 }
 
+// Lanes per wave for the one-chain-per-lane kernels.  `waves_per_simd` waves of such a kernel fit a SIMD (1 for the
+// 6-state kernels, 2 for the 3-state ones).  If cn/64 waves exceed what is resident at once, the launch would run
+// in rounds and the last round would leave most SIMDs idle while its few waves are limited by what ONE compute unit
+// can pull from memory; narrower waves, a multiple of 8 lanes (64-byte segments), make every round equally full.
+// EPIEKF_LANES=n overrides (measurement).
+static int balanced_lanes(int cn, int waves_per_simd)
+{
+    static int simds = 0;
+    if (!simds) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        simds = cus * 4;
+    }
+    if (const char *env = getenv("EPIEKF_LANES")) {
+        const int v = atoi(env);
+        if (v >= 1 && v <= kWave) return v;
+    }
+    const long cap = (long)simds * waves_per_simd;
+    const long w64 = (cn + kWave - 1) / kWave;
+    if (w64 <= cap) return kWave;
+    const long rounds = (w64 + cap - 1) / cap;
+    long lw = (cn + rounds * cap - 1) / (rounds * cap);
+    lw = (lw + 7) / 8 * 8;
+    return (int)(lw > kWave ? kWave : lw);
+}
+
 // phase: 0 = everything; 1 = forward kernel; 2 = smoother (pinv + backward); 3 = pinv kernel; 4 = backward kernel
 template <int M, int FLIP, int GENERIC>
 static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth, int hint, size_t shmem, hipStream_t st)
 {
     ka.c0 = c0; ka.cn = cn;
-    const int blocks = (cn + kWave - 1) / kWave;
+    ka.lw = balanced_lanes(cn, M == 6 ? 1 : 2);
+    const int blocks = (cn + ka.lw - 1) / ka.lw;
     const bool run_sym = GENERIC && hint != 2, run_dense = !GENERIC || hint != 1;
     hipError_t e = hipSuccess;
     if (phase == 0 || phase == 1) {
@@ -660,8 +727,7 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
     }
     if (!smooth) return e;
     if (GENERIC && ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
-        const size_t items = (size_t)(ka.T - 1) * cn;
-        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, ka);
+        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + 255) / 256), (unsigned)(ka.T - 1)), dim3(256), 0, st, ka);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phase == 0 || phase == 2 || phase == 4) {
@@ -781,6 +847,8 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->abi_version != EPIEKF_ABI_VERSION) { set_err(err, "ABI version mismatch"); return EPI_ERR_BAD_ARG; }
     if (d->model < 0 || d->model > 5) { set_err(err, "unknown model"); return EPI_ERR_BAD_ARG; }
     if (d->B < 1 || d->T < 1 || d->Sx < 1 || d->Su < 1 || d->L < 1) { set_err(err, "B, T, Sx, Su, L must be >= 1"); return EPI_ERR_BAD_ARG; }
+    if (d->T > 65536) { set_err(err, "T is limited to 65536 (grid y dimension of eks_pinv)"); return EPI_ERR_BAD_ARG; }
+    if (d->B > (1 << 23) || d->Sx > (1 << 23) || d->Su > (1 << 23)) { set_err(err, "B, Sx, Su are limited to 2^23 (a per-step array slice is addressed through one 4 GiB buffer descriptor)"); return EPI_ERR_BAD_ARG; }
     if (d->n_npi < 1 || d->n_npi > EPI_MAX_NPI) { set_err(err, "n_npi out of range 1..12"); return EPI_ERR_BAD_ARG; }
     if (d->order != 1 && d->order != 2) { set_err(err, epi_status_string(EPI_ERR_UNDEFINED_ORDER)); return EPI_ERR_UNDEFINED_ORDER; }
     const ModelInfo &mi = MODEL_TABLE[d->model];
