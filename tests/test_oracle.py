@@ -226,3 +226,15 @@ def test_simulators_and_cost_two_restatements_agree():
     lib.orc_npi_cost(dp(sn * inn * an), dp(u, "F"), dp(wts, "F"), C.c_int(n), C.c_int(K), C.byref(J0), C.byref(J1))
     j0, j1 = enp.npi_cost(sn * inn * an, u, wts)
     assert abs(J0.value - j0) <= 1e-14 * abs(j0) and abs(J1.value - j1) <= 1e-13 * abs(j1)
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """CPU sanitizer run (GPU ASan is unavailable on the pool): every model variant, batched driver, pinv,
+    mrdivide and the simulators under -fsanitize=address,undefined."""
+    import os
+    import subprocess
+    root = H.ROOT
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "selftest_asan"], stdout=subprocess.DEVNULL)
+    res = subprocess.run([os.path.join(root, "oracle", "selftest_asan")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count(" ok") == 7
