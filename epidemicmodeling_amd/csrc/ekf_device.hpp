@@ -452,15 +452,21 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped)
             rank++;
             const double inv = 1.0 / sv;
             const double sg = (d[i] < 0.0) ? -1.0 : 1.0;
+            // symmetric by construction: accumulate the upper triangle, mirror afterwards
 #pragma unroll
             for (int c = 0; c < M; c++)
 #pragma unroll
-                for (int r = 0; r < M; r++)
+                for (int r = 0; r <= c; r++)
                     X[IXM(r, c)] = fma(v[IXM(r, i)] * inv, sg * v[IXM(c, i)], X[IXM(r, c)]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < M * M; i++) X[i] = ldexp(X[i], -e);
+    for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int r = 0; r <= c; r++) {
+            X[IXM(r, c)] = ldexp(X[IXM(r, c)], -e);
+            X[IXM(c, r)] = X[IXM(r, c)];
+        }
     return rank;
 }
 

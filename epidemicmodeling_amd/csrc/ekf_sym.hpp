@@ -358,7 +358,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         load_sym<M>(a.P_PLUS, t, B, c, d.Pp);
         load_u(a, t, su, d.u);
         d.rk = ldg_i(a.rankbuf + (size_t)t1 * B, (unsigned)c * 4u);
-        load_mat<M>(a.X, t1, B, c, d.X);          // unused garbage where the :211 guard fired (rk < 0)
+        load_packed<M>(a.X, t1, B, c, d.X);       // unused garbage where the :211 guard fired (rk < 0)
         load_vec<M>(a.S_MINUS, t1, B, c, d.Sm1);
         load_sym<M>(a.P_MINUS, t1, B, c, d.Pm1);
     };

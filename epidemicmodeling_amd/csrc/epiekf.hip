@@ -120,6 +120,22 @@ EPI_DEV void load_mat(const double *__restrict__ src, int t, int B, int c, doubl
 #pragma unroll
     for (int e = 0; e < M * M; e++) P[e] = bld(r, voff, (unsigned)e * rowb);
 }
+// full symmetric matrix from a packed upper-triangle array [T][M(M+1)/2][B]
+template <int M>
+EPI_DEV void load_packed(const double *__restrict__ src, int t, int B, int c, double (&P)[M * M])
+{
+    constexpr int NSX = M * (M + 1) / 2;
+    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
+    const rsrc_t r = mk_rsrc(src + (size_t)t * NSX * B, (unsigned)NSX * rowb);
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i <= j; i++) {
+            const double v = bld(r, voff, (unsigned)(i + j * (j + 1) / 2) * rowb);
+            P[IXM(i, j)] = v;
+            P[IXM(j, i)] = v;
+        }
+}
 EPI_DEV void load_u(const KArgs &a, int t, int su, double (&u)[kNpi])
 {
     const unsigned voff = (unsigned)su * 8u, rowb = (unsigned)a.Su * 8u;
@@ -336,7 +352,15 @@ __global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
     double X[M * M];
     bool capped;
     const int rank = sym_pinv<M>(P, X, &capped);           // :215
-    store_mat<M>(a.X, t1, B, c, X);
+    {   // X is symmetric bit for bit: the workspace holds its packed upper triangle, [T][M(M+1)/2][B]
+        constexpr int NSX = M * (M + 1) / 2;
+        const unsigned rowb = (unsigned)B * 8u;
+        const rsrc_t r = mk_rsrc(a.X + (size_t)t1 * NSX * B, (unsigned)NSX * rowb);
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i <= j; i++) bst(r, voff, (unsigned)(i + j * (j + 1) / 2) * rowb, X[IXM(i, j)]);
+    }
     stg_i(rrow, (unsigned)c * 4u, rank | (capped ? 0x100 : 0));
 }
 
@@ -424,7 +448,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
                     st_guard = 1;
                 } else {
                     double X[M * M];
-                    load_mat<M>(a.X, t1, B, c, X);
+                    load_packed<M>(a.X, t1, B, c, X);
                     mat_mul<M>(PAt, X, J);                     // :215
                     rank = rk & 0xff;
                     st_cap |= (rk >> 8) & 1;
@@ -639,7 +663,7 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.p_plus = take(!(d->out_mask & EPI_OUT_P_PLUS), nP);
     // smoother intermediates of the generic models: X = pinv(P_MINUS) and its rank word per (step, chain)
     const bool generic = MODEL_TABLE[d->model].generic;
-    w.x = take(generic, nP);
+    w.x = take(generic, (size_t)d->T * (m * (m + 1) / 2) * d->B * sizeof(double));   // packed upper triangle of X
     w.rank = take(generic, (size_t)d->T * d->B * sizeof(int32_t));
     w.flag = take(generic, 256);
     w.total = off;

@@ -79,7 +79,8 @@ static void symmetrize(int m, double *P) /* P = (P + P')/2.0 */
  * triplets are (|lambda_i|, sign(lambda_i) v_i, v_i).  The eigen-decomposition is
  * the cyclic Jacobi method (Rutishauser / Numerical-Recipes formulation with the
  * b/z accumulators), run on A scaled by an exact power of two.  The kept terms
- * are accumulated in the eigenvalue index order the iteration leaves them in. */
+ * are accumulated in the eigenvalue index order the iteration leaves them in;
+ * only the upper triangle of X is accumulated and then mirrored. */
 static double eps_of(double x) /* MATLAB eps(x) for finite x >= 0 */
 {
     if (x == 0.0) return 4.9406564584124654e-324;
@@ -178,11 +179,17 @@ int orc_sym_pinv(int m, const double *A, double *X)
         rank++;
         double inv = 1.0 / sv;
         double sg = (d[i] < 0.0) ? -1.0 : 1.0;
+        /* the pseudo-inverse of a symmetric matrix is symmetric: the upper triangle is accumulated and
+         * mirrored, so that X is symmetric bit for bit (and can be stored packed) */
         for (int c = 0; c < m; c++)
-            for (int r = 0; r < m; r++)
+            for (int r = 0; r <= c; r++)
                 X[IX(r, c, m)] = fma(v[IX(r, i, m)] * inv, sg * v[IX(c, i, m)], X[IX(r, c, m)]);
     }
-    for (int i = 0; i < m * m; i++) X[i] = ldexp(X[i], -e);
+    for (int c = 0; c < m; c++)
+        for (int r = 0; r <= c; r++) {
+            X[IX(r, c, m)] = ldexp(X[IX(r, c, m)], -e);
+            X[IX(c, r, m)] = X[IX(r, c, m)];
+        }
     return rank;
 }
 
