@@ -378,33 +378,36 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
         for (int p = 0; p < M - 1; p++) {
 #pragma unroll
             for (int q = p + 1; q < M; q++) {
+                // Same decisions and the same arithmetic as the scalar formulation (oracle/ekf_oracle.c), arranged
+                // for a wavefront: the pair is skipped only if NO lane rotates it (wave-uniform branch, no exec-mask
+                // bookkeeping); inside, every lane applies a rotation, the identity (t = 0 => c = 1, s = tau = 0,
+                // which leaves every operand bit-wise unchanged) for the lanes that do not rotate.
                 const double apq = a[IXM(p, q)];
                 const double g = 100.0 * fabs(apq);
-                if (sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q])) {
-                    a[IXM(p, q)] = 0.0;
-                } else if (fabs(apq) > tresh) {
-                    double h = d[q] - d[p];
-                    double t;
-                    if ((fabs(h) + g) == fabs(h)) {
-                        t = apq / h;
-                    } else {
-                        // t = sgn(theta)/(|theta| + sqrt(theta^2+1)), theta = h/(2 apq), times |2 apq| through
-                        const double two_apq = 2.0 * apq;
-                        t = two_apq / (fabs(h) + sqrt(fma(h, h, two_apq * two_apq)));
-                        if (h < 0.0) t = -t;
-                    }
+                const bool negl = sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q]);
+                const bool rot = !negl && (fabs(apq) > tresh);
+                if (__builtin_amdgcn_ballot_w64(rot) != 0ull) {
+                    const double hd = d[q] - d[p];
+                    const bool small = (fabs(hd) + g) == fabs(hd);
+                    // t = apq/h, or sgn(theta)/(|theta| + sqrt(theta^2+1)) with theta = h/(2 apq) scaled by |2 apq|
+                    const double two_apq = 2.0 * apq;
+                    const double w = sqrt(fma(hd, hd, two_apq * two_apq));
+                    const double num = small ? apq : two_apq;
+                    const double den = small ? hd : (fabs(hd) + w);
+                    double t = num / den;
+                    if (!small && hd < 0.0) t = -t;
+                    t = rot ? t : 0.0;
                     // c = 1/r, tau = s/(1+c) = t/(1+r), r = sqrt(1+t^2): one division serves both
                     const double r = sqrt(fma(t, t, 1.0));
                     const double ir = 1.0 / fma(r, r, r);
                     const double c = (1.0 + r) * ir;
                     const double s = t * c;
                     const double tau = (t * r) * ir;
-                    h = t * apq;
+                    const double h = t * apq;
                     z[p] = z[p] - h;
                     z[q] = z[q] + h;
                     d[p] = d[p] - h;
                     d[q] = d[q] + h;
-                    a[IXM(p, q)] = 0.0;
 #pragma unroll
                     for (int j = 0; j < p; j++) jacobi_rot<M>(a[IXM(j, p)], a[IXM(j, q)], s, tau);
 #pragma unroll
@@ -414,6 +417,7 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
 #pragma unroll
                     for (int j = 0; j < M; j++) jacobi_rot<M>(v[IXM(j, p)], v[IXM(j, q)], s, tau);
                 }
+                a[IXM(p, q)] = (negl || rot) ? 0.0 : apq;
             }
         }
 #pragma unroll
