@@ -143,13 +143,10 @@ def gather_to_root(t: torch.Tensor, group=None, dst: int = 0):
     world = dist.get_world_size(group)
     if world == 1:
         return [t]
-    if dist.get_backend(group) == "nccl":
-        # ncclSend/ncclRecv grouped by torch's gather implementation
-        bufs = [torch.empty_like(t) for _ in range(world)] if dist.get_rank(group) == dst else None
-        dist.gather(t, bufs, dst=dst, group=group)
-        return bufs
+    if dist.get_backend(group) != "nccl":
+        t = t.cpu()                     # gloo rehearsal / CPU tests: the gather goes through host memory
     bufs = [torch.empty_like(t) for _ in range(world)] if dist.get_rank(group) == dst else None
-    dist.gather(t, bufs, dst=dst, group=group)
+    dist.gather(t, bufs, dst=dst, group=group)      # RCCL: one send per peer, each on its own xGMI link
     return bufs
 
 

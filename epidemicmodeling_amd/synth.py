@@ -443,3 +443,23 @@ def as_backward(w: Workload) -> Workload:
     out.s_final[:3] = w.meta["truth_end"]
     out.Ps_final = w.Ps_init.copy()
     return out
+
+
+def make_mask_ensemble(n_regions: int = 8, T: int = 200, num_forecast_days: int = 30) -> Workload:
+    """Look-ahead quality study of Tools/ForecastQualityAssessment.m:383-386 as ONE batch: for every region and
+    every start = 1..num_forecast_days a 3-state chain whose last `start` observations are NaN.  The chains of a
+    region share its controls (u_series) and R_v; each has its own masked observation column (Sx == B)."""
+    base = make_cfg3(n_regions, T)
+    B = n_regions * num_forecast_days
+    rr = np.repeat(np.arange(n_regions), num_forecast_days)
+    start = np.tile(np.arange(1, num_forecast_days + 1), n_regions)
+    x = base.x[:, rr].copy()
+    tt = np.arange(T)[:, None]
+    x[tt >= (T - start)[None, :]] = np.nan                          # observations_PARTIAL(LL-start+1:LL) = nan
+    return Workload(model="SIAlphaModelEKF", T=T, n_npi=NUM_NPI, x=np.ascontiguousarray(x), u=base.u,
+                    R_series=np.ascontiguousarray(base.R_series[:, rr]), R_scalar=None, x_series=None,
+                    u_series=rr.astype(np.int32), prm=np.ascontiguousarray(base.prm[:, rr]),
+                    s_init=np.ascontiguousarray(base.s_init[:, rr]), Ps_init=np.ascontiguousarray(base.Ps_init[:, rr]),
+                    s_final=np.full((3, B), np.nan), Ps_final=np.full((9, B), np.nan),
+                    Q=np.ascontiguousarray(base.Q[:, rr]),
+                    meta={"workload": "mask_ensemble", "regions": n_regions, "num_forecast_days": num_forecast_days})
