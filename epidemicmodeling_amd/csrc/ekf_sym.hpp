@@ -53,7 +53,7 @@ EPI_DEV void load_sym(const double *__restrict__ src, int t, int B, int c, doubl
 }
 
 // ---------------------------------------------------------------------------
-// pre-check: may this batch take the symmetric fast path?  (Ps_init bit-wise symmetric, Q_w diagonal)
+// pre-check: may this batch take the symmetric fast path?  (Ps_init and Ps_final bit-wise symmetric, Q_w diagonal)
 // ---------------------------------------------------------------------------
 template <int M>
 __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restrict__ flag, int force_dense)
@@ -70,7 +70,11 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
             const double pu = a.Ps_init[(size_t)IXM(i, j) * B + c], pl = a.Ps_init[(size_t)IXM(j, i) * B + c];
             const bool same = (pu == pl) || (is_nan(pu) && is_nan(pl));
             const double qu = a.Q[(size_t)IXM(i, j) * B + c], ql = a.Q[(size_t)IXM(j, i) * B + c];
-            dense = dense || !same || !(qu == 0.0) || !(ql == 0.0);
+            // the end-point covariance overrides P_SMOOTH(:,:,T) entry by entry (GenericEKF.m:198-202): the
+            // packed smoother needs the result symmetric, i.e. Ps_final symmetric in values and NaN pattern
+            const double fu = a.Ps_final[(size_t)IXM(i, j) * B + c], fl = a.Ps_final[(size_t)IXM(j, i) * B + c];
+            const bool fsame = (fu == fl) || (is_nan(fu) && is_nan(fl));
+            dense = dense || !same || !fsame || !(qu == 0.0) || !(ql == 0.0);
         }
     if (dense) atomicOr(flag, 1);
 }
@@ -319,8 +323,8 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         vlds[(3 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
     }
 
-    // terminal conditions GenericEKF.m:189-202.  Ps_final is applied entry by entry, so P_SMOOTH(:,:,T)
-    // is only symmetric if Ps_final is: it is kept as a full matrix for the first step.
+    // terminal conditions GenericEKF.m:189-202.  Ps_final overrides entry by entry; ekf_precheck guarantees it
+    // is symmetric (values and NaN pattern), so P_SMOOTH(:,:,T) is symmetric and stays packed.
     double Ss[M], Ps[NS];
     const int tT = tpos<FLIP>(T - 1, T);
     load_vec<M>(a.S_PLUS, tT, B, c, Ss);
@@ -329,15 +333,16 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         const double f = a.s_final[(size_t)i * B + c];
         if (!is_nan(f)) Ss[i] = f;
     }
-    double PsT[M * M];
-    load_mat<M>(a.P_PLUS, tT, B, c, PsT);
+    load_sym<M>(a.P_PLUS, tT, B, c, Ps);
 #pragma unroll
-    for (int e = 0; e < M * M; e++) {
-        const double f = a.Ps_final[(size_t)e * B + c];
-        if (!is_nan(f)) PsT[e] = f;
-    }
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i <= j; i++) {
+            const double f = a.Ps_final[(size_t)IXM(i, j) * B + c];
+            if (!is_nan(f)) Ps[sidx(i, j)] = f;
+        }
     store_vec<M>(a.S_SMOOTH, tT, B, c, Ss);
-    store_mat<M>(a.P_SMOOTH, tT, B, c, PsT);
+    store_sym<M>(a.P_SMOOTH, tT, B, c, Ps);
     if (a.u_opt_smooth) {
         double z[kNpi];
 #pragma unroll
@@ -374,8 +379,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         if (a.u_opt_smooth) store_u(a.u_opt_smooth, a, t_pend, c, u_pend);
     };
 
-    auto step = [&](int k, auto first_tag) {
-        constexpr bool first_step = decltype(first_tag)::value;
+    auto step = [&](int k) {
         const int t = tpos<FLIP>(k, T);
         fetch(k, cur);
         flush();
@@ -433,28 +437,20 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         state_hard_margins<M>(p, Sn);                          // :221
         {
             // P_SMOOTH(k) = sym(P+ - (J D) J'),  D = P_MINUS(k+1) - P_SMOOTH(k+1)   :223-226
-            // D is symmetric except possibly at the first step (Ps_final overrides); rows of J D are consumed
-            // one at a time and paired entries are averaged as soon as both exist (see ekf_fwd_sym)
-            double Dfull[first_step ? M * M : 1], Dsym[first_step ? 1 : NS];
-            if (first_step) {
+            // rows of J D are consumed one at a time and paired entries are averaged as soon as both exist
+            // (see ekf_fwd_sym)
+            double Dsym[NS];
 #pragma unroll
-                for (int j = 0; j < M; j++)
-#pragma unroll
-                    for (int i = 0; i < M; i++) Dfull[IXM(i, j)] = cur.Pm1[sidx(i, j)] - PsT[IXM(i, j)];
-            } else {
-#pragma unroll
-                for (int e = 0; e < NS; e++) Dsym[e] = cur.Pm1[e] - Ps[e];
-            }
+            for (int e = 0; e < NS; e++) Dsym[e] = cur.Pm1[e] - Ps[e];
             double F[M * M];
 #pragma unroll
             for (int i = 0; i < M; i++) {
                 double T1r[M];
 #pragma unroll
                 for (int j = 0; j < M; j++) {
-                    double acc = J[IXM(i, 0)] * (first_step ? Dfull[IXM(0, j)] : Dsym[sidx(0, j)]);
+                    double acc = J[IXM(i, 0)] * Dsym[sidx(0, j)];
 #pragma unroll
-                    for (int q = 1; q < M; q++)
-                        acc = fma(J[IXM(i, q)], first_step ? Dfull[IXM(q, j)] : Dsym[sidx(q, j)], acc);
+                    for (int q = 1; q < M; q++) acc = fma(J[IXM(i, q)], Dsym[sidx(q, j)], acc);
                     T1r[j] = acc;
                 }
 #pragma unroll
@@ -480,8 +476,8 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         t_pend = t;
         rank_pend = rank;
     };
-    if (T >= 2) step(T - 2, std::true_type{});
-    for (int k = T - 3; k >= 0; k--) step(k, std::false_type{});
+    for (int k = T - 2; k >= 0; k--) step(k);
     flush();
     if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }
+

@@ -987,6 +987,7 @@ int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void 
     KArgs ka{};
     ka.B = d->B;
     ka.Ps_init = mi.flipped ? in->Ps_final : in->Ps_init;
+    ka.Ps_final = mi.flipped ? in->Ps_init : in->Ps_final;
     ka.Q = in->Q;
     int *flag = nullptr;
     hipError_t e = hipMalloc((void **)&flag, sizeof(int));
