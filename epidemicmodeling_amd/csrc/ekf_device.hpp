@@ -40,17 +40,8 @@ struct ChainPrm {
     EPI_DEV double W(int k) const { return w[k]; }
 };
 
-// the same constants with the four 12-vectors (a, u_min, u_max, w) left where they are -- in the prm
-// array (re-read through L2 when a step needs them) or in an LDS column -- so that they do not occupy
-// 96 VGPRs for the whole life of the chain
-struct VecGlobal {
-    const double *__restrict__ prm;
-    int B, c;
-    EPI_DEV double A(int k) const { return prm[(size_t)(EPI_PRM_A + k) * B + c]; }
-    EPI_DEV double Umin(int k) const { return prm[(size_t)(EPI_PRM_U_MIN + k) * B + c]; }
-    EPI_DEV double Umax(int k) const { return prm[(size_t)(EPI_PRM_U_MAX + k) * B + c]; }
-    EPI_DEV double W(int k) const { return prm[(size_t)(EPI_PRM_W_EFF + k) * B + c]; }
-};
+// the same constants with the four 12-vectors (a, u_min, u_max, w) kept in an LDS column per lane, so that
+// they do not occupy 96 VGPRs for the whole life of the chain
 struct VecLds {
     const double *base;   // this lane's column of a [4][12][64] block: a, u_min, u_max, w
     EPI_DEV double A(int k) const { return base[(0 * kNpi + k) * kWave]; }

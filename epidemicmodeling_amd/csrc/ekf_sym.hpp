@@ -10,9 +10,9 @@
 //    operands fma(a, 0, acc) == acc, so skipping them is exact; a chain whose covariance has overflowed
 //    to Inf/NaN can differ from the dense evaluation in WHERE the non-finite values sit (both are
 //    garbage there; status bit 0 / the J = 0 guard of :211 still fire) -- DESIGN.md "Arithmetic contract";
-//  * the four 12-vectors of `params` stay in memory (L2) / LDS instead of 96 VGPRs.
-// Net effect: <= 256 VGPRs, i.e. two waves per SIMD, so all B/64 waves of the headline sweep are
-// resident at once instead of running in two rounds.
+//  * the smoother keeps the four 12-vectors of `params` in an LDS column per lane instead of 96 VGPRs.
+// Net effect for m = 6: about half the fp64 operations and 380-410 instead of 494-512 VGPRs (no scratch); still
+// one wave per SIMD -- see DESIGN.md "Occupancy and the wave-count quantum" for what was tried to get to two.
 #pragma once
 
 template <int M> constexpr int nsym() { return M * (M + 1) / 2; }
