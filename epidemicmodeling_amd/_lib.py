@@ -117,7 +117,7 @@ def check(rc: int, err_buf) -> None:
         raise EpiError(rc, msg)
 
 
-def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask) -> BatchDesc:
+def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask, q_mode=0) -> BatchDesc:
     d = BatchDesc()
     d.abi_version = 1
     d.model = L.MODEL_IDS[model] if isinstance(model, str) else int(model)
@@ -126,6 +126,6 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask)
         d.obs_type = L.OBS_IDS.get(obs_type, 99)   # unknown strings reach the library's own check
     else:
         d.obs_type = int(obs_type)
-    d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), 0, int(out_mask), 0
+    d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), int(q_mode), int(out_mask), 0
     d.path_hint, d.chunks = 0, 0
     return d

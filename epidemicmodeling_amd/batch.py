@@ -43,6 +43,7 @@ class DeviceWorkload:
         self.prm, self.s_init, self.Ps_init = f(w.prm), f(w.s_init), f(w.Ps_init)
         self.s_final, self.Ps_final, self.Q = f(w.s_final), f(w.Ps_final), f(w.Q)
         self.r_mode = 1 if w.R_series is not None else 0
+        self.q_mode = 1 if np.ndim(w.Q) == 3 else 0     # Q [T][m*m][B]: Q(:,:,k) per filter step
 
     def inputs_struct(self):
         s = _lib.Inputs()
@@ -72,7 +73,7 @@ class EkfRunner:
         self.names = names
         self.mask = out_mask_of(names)
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
-                                   dw.r_mode, self.mask)
+                                   dw.r_mode, self.mask, dw.q_mode)
         self.err = C.create_string_buffer(256)
         h = _lib.lib()
         _lib.check(h.epi_ekf_validate(C.byref(self.desc), self.err), self.err)

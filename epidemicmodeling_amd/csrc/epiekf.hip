@@ -29,6 +29,7 @@ static const ModelInfo MODEL_TABLE[6] = {
 
 struct KArgs {
     int B, T, Sx, Su, n_npi, L, r_mode;
+    int q_mode;   // 1: Q is [T][m*m][B], Q(:,:,k) of filter step k (GenericEKF.m:63-73); dense kernels only
     ModelFlags mf;
     const int32_t *x_series, *u_series;
     const double *x, *u, *R_series, *R_scalar, *prm;
@@ -197,6 +198,8 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
         const double xk = a.x[(size_t)t * a.Sx + sx];
         double u_in[kNpi];
         load_u(a, t, su, u_in);
+        if (GENERIC && a.q_mode)   // Q(:,:,k): like R_v, Q_w is not time-flipped by the backward wrappers
+            load_mat<M>(a.Q, k, B, c, Q);
 
         store_vec<M>(a.S_MINUS, t, B, c, sk_minus);       // :100-101
         store_mat<M>(a.P_MINUS, t, B, c, Pk_minus);
@@ -879,7 +882,10 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (!mi.obs_fixed && d->obs_type != EPI_OBS_NEWCASES && d->obs_type != EPI_OBS_TOTALCASES) {
         set_err(err, epi_status_string(EPI_ERR_OBS_TYPE)); return EPI_ERR_OBS_TYPE;
     }
-    if (d->q_mode != 0) { set_err(err, epi_status_string(EPI_ERR_Q_MISMATCH)); return EPI_ERR_Q_MISMATCH; }
+    if (d->q_mode != 0 && d->q_mode != 1) { set_err(err, epi_status_string(EPI_ERR_Q_MISMATCH)); return EPI_ERR_Q_MISMATCH; }
+    if (!mi.generic && d->q_mode != 0) {   // NewCase...m:30  Q = Q_w is added to an m x m matrix as it is
+        set_err(err, epi_status_string(EPI_ERR_Q_MISMATCH)); return EPI_ERR_Q_MISMATCH;
+    }
     if (d->r_mode != 0 && d->r_mode != 1) { set_err(err, epi_status_string(EPI_ERR_R_MISMATCH)); return EPI_ERR_R_MISMATCH; }
     if (!mi.generic && d->r_mode != 0) {   // NewCase...m:31  R = R_v is used as a scalar
         set_err(err, epi_status_string(EPI_ERR_R_MISMATCH)); return EPI_ERR_R_MISMATCH;
@@ -920,7 +926,7 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     auto sel = [&](uint32_t bit, double *p) -> double * { return (om & bit) ? p : nullptr; };
     char *ws = (char *)workspace;
     KArgs ka{};
-    ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode;
+    ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode; ka.q_mode = d->q_mode;
     ka.mf.lo_is_zero = mi.lo_is_zero; ka.mf.phi_ge = mi.phi_ge; ka.mf.obs_clamp = mi.obs_clamp;
     ka.mf.obs_type = mi.obs_fixed ? EPI_OBS_NEWCASES : d->obs_type;
     ka.x_series = in->x_series; ka.u_series = in->u_series;
@@ -963,7 +969,8 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     hipStream_t st = (hipStream_t)stream;
     int chunks = d->chunks;
     if (chunks > kMaxChunks) chunks = kMaxChunks;
-    const int hint = mi.generic ? d->path_hint : 2;
+    // a time-varying Q_w is read per step by the dense kernels only
+    const int hint = (mi.generic && d->q_mode == 0) ? d->path_hint : 2;
     hipError_t e;
     switch (d->model) {
     case EPI_MODEL_SIA3: e = launch_chain<3, 0, 1>(ka, d->phase, smooth, hint, chunks, st); break;
@@ -983,7 +990,7 @@ int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void 
     if (!in || !fast_ok || !in->Ps_init || !in->Ps_final || !in->Q) { set_err(err, "NULL argument"); return EPI_ERR_BAD_ARG; }
     const ModelInfo &mi = MODEL_TABLE[d->model];
     *fast_ok = 0;
-    if (!mi.generic) return EPI_OK;   // the NewCase models never symmetrise: dense kernels only
+    if (!mi.generic || d->q_mode != 0) return EPI_OK;   // NewCase models never symmetrise; Q(:,:,k): dense kernels only
     KArgs ka{};
     ka.B = d->B;
     ka.Ps_init = mi.flipped ? in->Ps_final : in->Ps_init;
@@ -1033,7 +1040,7 @@ int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_ou
     UP(x, T * d->Sx * 8); UP(u, T * d->n_npi * d->Su * 8);
     if (d->r_mode == 1) { UP(R_series, T * d->Sx * 8); } else { UP(R_scalar, B * 8); }
     UP(prm, (size_t)EPI_PRM_COUNT * B * 8);
-    UP(s_init, m * B * 8); UP(Ps_init, mm * B * 8); UP(s_final, m * B * 8); UP(Ps_final, mm * B * 8); UP(Q, mm * B * 8);
+    UP(s_init, m * B * 8); UP(Ps_init, mm * B * 8); UP(s_final, m * B * 8); UP(Ps_final, mm * B * 8); UP(Q, (d->q_mode ? T : (size_t)1) * mm * B * 8);
 #undef UP
     struct O { uint32_t bit; double *const *host; double **dev; size_t bytes; };
     const size_t nU = T * d->n_npi * B * 8, nS = T * m * B * 8, nP = T * mm * B * 8, n1 = T * B * 8;

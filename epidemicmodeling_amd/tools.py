@@ -102,19 +102,26 @@ def _run(model, u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, 
     prm[L.PRM_V_BAR] = float(np.asarray(v_bar).reshape(-1)[0])
     prm[L.PRM_BETA_EKF] = float(beta); prm[L.PRM_GAMMA_EKF] = float(gamma)
 
-    # Q_w: GenericExtendedKalmanFilter.m:64-76
+    # Q_w: GenericExtendedKalmanFilter.m:63-76.  The first test (size(Q_w,1) == size(Q_w,2)) also catches
+    # m x m x D arrays: Q = repmat(Q_w,1,1,T) makes Q(:,:,k) = Q_w(:,:,mod(k-1,D)+1), i.e. the pages are used
+    # cyclically (time-varying when D == T); a length-T vector is q(k) in B*Q*B' with B = eye(m).
     Q = np.asarray(Q_w, dtype=np.float64)
+    generic = not model.startswith("NewCase")
+    q_mode, Qt = 0, None
     if Q.ndim <= 2 and Q.size == 1:
         Qm = float(Q.reshape(-1)[0]) * np.eye(m)          # B*Q*B' with B = eye(m)
     elif Q.ndim == 2 and Q.shape == (m, m):
         Qm = Q
-    elif (Q.ndim == 3 and Q.shape[:2] == (m, m) and Q.shape[2] == T) or ((Q.ndim == 1 or (Q.ndim == 2 and min(Q.shape) == 1)) and Q.size == T):
-        raise EpiError(-8, "time-varying Q_w is valid in the reference but not supported by this engine")
+    elif generic and Q.ndim == 3 and Q.shape[:2] == (m, m):
+        q_mode, Qt = 1, Q[:, :, np.arange(T) % Q.shape[2]]
+    elif generic and Q.ndim == 3 and Q.shape[:2] == (1, 1):
+        q_mode, Qt = 1, Q[0, 0, np.arange(T) % Q.shape[2]][None, None, :] * np.eye(m)[:, :, None]
+    elif generic and (Q.ndim == 1 or (Q.ndim == 2 and min(Q.shape) == 1)) and Q.size == T:
+        q_mode, Qt = 1, Q.reshape(-1)[None, None, :] * np.eye(m)[:, :, None]
     else:
         raise EpiError(-2, "Process noise covariance noise mismatch")
     # R_v: GenericExtendedKalmanFilter.m:79-91
     R = np.asarray(R_v, dtype=np.float64)
-    generic = not model.startswith("NewCase")
     if R.size == 1:
         r_mode, R_scalar, R_series = 0, np.array([float(R.reshape(-1)[0])]), None
     elif generic and (R.ndim == 1 or (R.ndim == 2 and min(R.shape) == 1)) and R.size == T:   # isvector && length == T
@@ -127,7 +134,11 @@ def _run(model, u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, 
     si, sf = col(s_init, m), col(s_final, m)
     if sf is None:
         raise ValueError(f"length(s_final) must be {m}")
-    Pi, Pf, Qc = fcol(Ps_init), fcol(Ps_final), fcol(Qm)
+    Pi, Pf = fcol(Ps_init), fcol(Ps_final)
+    if q_mode:   # [T][m*m][1], pages column-major like every matrix of the ABI
+        Qc = np.ascontiguousarray(Qt.transpose(2, 1, 0).reshape(T, m * m, 1))
+    else:
+        Qc = fcol(Qm)
     xs = np.ascontiguousarray(x.reshape(T, 1))
     us = np.ascontiguousarray(u.T.reshape(T, nn, 1))      # [T][n_npi][1] == MATLAB column-major n_npi x T
 
@@ -139,7 +150,7 @@ def _run(model, u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, 
     mask = 0
     for n_ in names:
         mask |= L.OUT_BITS[n_]
-    desc = _lib.make_desc(model, 1, T, 1, 1, nn, int(inv_monitor_len), int(order), _get(params, "obs_type") if "obs_type" in _FIELDS[model] else "NEWCASES", r_mode, mask)
+    desc = _lib.make_desc(model, 1, T, 1, 1, nn, int(inv_monitor_len), int(order), _get(params, "obs_type") if "obs_type" in _FIELDS[model] else "NEWCASES", r_mode, mask, q_mode)
     out = {n_: np.zeros((T, max(L.out_rows(n_, m, nn), 1), 1)) for n_ in names}
     ins, outs = _lib.Inputs(), _lib.Outputs()
     keep = [xs, us, prm, si, sf, Pi, Pf, Qc, R_scalar, R_series]

@@ -107,7 +107,9 @@ typedef struct epi_batch_desc {
                              Tools/SIAlphaModelEKF.m:92-109) */
     int32_t obs_type;     /* epi_obs_type */
     int32_t r_mode;       /* 0: R_scalar[B] (scalar R_v, adaptive when beta != 1); 1: R_series */
-    int32_t q_mode;       /* 0: fixed per-chain m x m Q_w (the only form the reference's callers use) */
+    int32_t q_mode;       /* 0: fixed per-chain m x m Q_w, Q [m*m][B] (the only form the reference's callers use);
+                             1: time-varying, Q [T][m*m][B] = Q(:,:,k) of filter step k (GenericEKF.m:63-73; a
+                                length-T vector Q_w is q(k)*eye(m)); generic models only, dense kernels */
     uint32_t out_mask;    /* epi_out bits: which outputs are written */
     int32_t phase;        /* 0: forward EKF then backward EKS (one reference call).  For per-kernel timing a
                              caller may enqueue the stages one by one, in order, on the same buffers:

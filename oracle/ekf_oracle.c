@@ -832,6 +832,7 @@ int orc_ekf_run_batch(const orc_batch *bt, int n_threads)
         double *inn = (double *)malloc(sizeof(double) * (size_t)T);
         double *rh = (double *)malloc(sizeof(double) * (size_t)T);
         int *rk = (int *)malloc(sizeof(int) * (size_t)T);
+        double *Qt = bt->q_mode ? (double *)malloc(sizeof(double) * (size_t)mm * T) : NULL;
 #pragma omp for schedule(dynamic, 4)
         for (int c = 0; c < B; c++) {
             const int sx = bt->x_series_of_chain ? bt->x_series_of_chain[c] : c;
@@ -862,7 +863,10 @@ int orc_ekf_run_batch(const orc_batch *bt, int n_threads)
                 Pi[i] = bt->Ps_init[(size_t)i * B + c]; Pf[i] = bt->Ps_final[(size_t)i * B + c];
                 Q[i] = bt->Q[(size_t)i * B + c];
             }
-            int rc = orc_ekf_run(bt->model, T, u, x, &p, si, Pi, sf, Pf, v_bar, Q, 1, Rv,
+            if (bt->q_mode)
+                for (int k = 0; k < T; k++)
+                    for (int i = 0; i < mm; i++) Qt[i + (size_t)mm * k] = bt->Q[((size_t)k * mm + i) * B + c];
+            int rc = orc_ekf_run(bt->model, T, u, x, &p, si, Pi, sf, Pf, v_bar, bt->q_mode ? Qt : Q, bt->q_mode ? T : 1, Rv,
                                  bt->r_mode == 1 ? T : 1, beta_ekf, gamma_ekf, bt->L, bt->order,
                                  uo, uos, SM, SP, SS, PM, PP, PS, KG, inn, rh, rk);
             if (rc != ORC_OK) {
@@ -893,7 +897,7 @@ int orc_ekf_run_batch(const orc_batch *bt, int n_threads)
             }
         }
         free(u); free(x); free(Rv); free(uo); free(uos); free(SM); free(SP); free(SS);
-        free(PM); free(PP); free(PS); free(KG); free(inn); free(rh); free(rk);
+        free(PM); free(PP); free(PS); free(KG); free(inn); free(rh); free(rk); free(Qt);
     }
     return rc_all;
 }

@@ -52,7 +52,7 @@ class _Batch(C.Structure):
         ("x_series_of_chain", C.c_void_p), ("u_series_of_chain", C.c_void_p)] + [(n, C.c_void_p) for n in (
             "x", "u", "R_series", "R_scalar", "prm", "s_init", "Ps_init", "s_final", "Ps_final", "Q",
             "u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "P_MINUS", "P_PLUS", "P_SMOOTH",
-            "K_GAIN", "innovations", "rho", "pinv_rank")]
+            "K_GAIN", "innovations", "rho", "pinv_rank")] + [("q_mode", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -180,6 +180,7 @@ def run_batch(model, T, n_npi, L, order, obs_type, x, u, prm, s_init, Ps_init, s
     bt.model, bt.B, bt.T, bt.Sx, bt.Su, bt.n_npi, bt.L, bt.order = mid, B, T, x.shape[1], u.shape[2], n_npi, L, order
     bt.obs_type = OBS_IDS[obs_type] if isinstance(obs_type, str) else int(obs_type)
     bt.r_mode = 1 if R_series is not None else 0
+    bt.q_mode = 1 if np.ndim(Q) == 3 else 0          # Q [T][m*m][B]
     keep = [x, u, prm]
     for name, mp in (("x_series_of_chain", x_series), ("u_series_of_chain", u_series)):
         if mp is None:

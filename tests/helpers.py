@@ -36,7 +36,10 @@ def chain_args(w, c):
     R_v = w.R_series[:, sx].copy() if w.R_series is not None else float(w.R_scalar[c])
     Pi = w.Ps_init[:, c].reshape(m, m, order="F")
     Pf = w.Ps_final[:, c].reshape(m, m, order="F")
-    Q = w.Q[:, c].reshape(m, m, order="F")
+    if np.ndim(w.Q) == 3:                                # time-varying: [T][m*m][B] -> m x m x T
+        Q = np.ascontiguousarray(w.Q[:, :, c].T).reshape(m, m, -1, order="F")
+    else:
+        Q = w.Q[:, c].reshape(m, m, order="F")
     return (u, x, p, w.s_init[:, c].copy(), Pi, w.s_final[:, c].copy(), Pf, np.zeros(m),
             float(w.prm[L.PRM_V_BAR, c]), Q, R_v, float(w.prm[L.PRM_BETA_EKF, c]),
             float(w.prm[L.PRM_GAMMA_EKF, c]), w.L, w.order)
@@ -128,3 +131,14 @@ def load_golden(name):
 
 GOLDEN_CASES = ["sia3_cfg3", "sia6_cfg4", "sia6_row3_adaptiveR", "newcase6_row4", "newcase6_codegen_row4",
                 "sia3_backward", "sia6_backward"]
+
+
+def with_time_varying_q(w, seed=0):
+    """Same workload with Q_w as an m x m x T array per chain (GenericExtendedKalmanFilter.m:63-73):
+    Q [T][m*m][B], each page the fixed Q scaled by a slowly varying positive factor."""
+    import copy
+    rng = np.random.default_rng(seed)
+    w2 = copy.copy(w)
+    scale = 1.0 + 0.5 * np.sin(np.arange(w.T) / 7.0)[:, None, None] + 0.1 * rng.random((w.T, 1, w.B))
+    w2.Q = np.ascontiguousarray(w.Q[None, :, :] * scale)
+    return w2

@@ -58,6 +58,8 @@ def _desc(**kw):
     (dict(obs_type="DEATHS"), -4, "unknown observation type"),
     (dict(r_mode=2), -3, "Observation noise covariance noise mismatch"),
     (dict(model="NewCaseEKFEstimatorWithOptimalNPI", r_mode=1), -3, "Observation noise covariance noise mismatch"),
+    (dict(q_mode=2), -2, "Process noise covariance noise mismatch"),
+    (dict(model="NewCaseEKFEstimatorWithOptimalNPI", r_mode=0, q_mode=1), -2, "Process noise covariance noise mismatch"),
     (dict(n_npi=13), -5, None), (dict(B=0), -5, None), (dict(L_=0), -5, None), (dict(L_=200), -8, None),
 ])
 def test_validate_mirrors_reference_errors(hip_lib, kw, code, msg):
@@ -71,6 +73,7 @@ def test_validate_mirrors_reference_errors(hip_lib, kw, code, msg):
 def test_validate_accepts_order_two_and_codegen_ignores_obs_type(hip_lib):
     err = C.create_string_buffer(256)
     assert hip_lib.epi_ekf_validate(C.byref(_desc(order=2)), err) == 0
+    assert hip_lib.epi_ekf_validate(C.byref(_desc(q_mode=1)), err) == 0     # m x m x T process noise
     d = _desc(model="NewCaseEKFEstimatorWithOptimalNPI_codegen", obs_type="whatever", r_mode=0)
     assert hip_lib.epi_ekf_validate(C.byref(d), err) == 0     # MatlabCodeGenerator/NlinObsUpdate.m has no obs_type
 
@@ -136,6 +139,8 @@ def test_tools_error_behaviour_matches_reference(hip_lib):
         _call3(R_v=np.ones(7))
     with pytest.raises(EpiError, match="Process noise covariance noise mismatch"):
         _call3(Q_w=np.ones((2, 3)))
+    with pytest.raises(EpiError, match="Process noise covariance noise mismatch"):
+        _call3(Q_w=np.ones(7))            # a vector Q_w must have length T
     p = _params3(); p["obs_type"] = "DEATHS"
     with pytest.raises(EpiError, match="unknown observation type"):
         _call3(params=p)

@@ -47,6 +47,28 @@ def test_c_oracle_matches_numpy_restatement(mk, chains):
         assert H.rowwise_abs_rel_err(H.batch_chain(ob, "S_SMOOTH", c, w.m)[:3], nd["S_SMOOTH"][:3]) <= 5e-2
 
 
+def test_time_varying_q_c_oracle_matches_numpy():
+    """Q_w as m x m x T (GenericExtendedKalmanFilter.m:63-73): page k is added at filter step k, and -- like
+    R_v -- it is not time-flipped by the backward wrappers."""
+    for mk in (lambda: synth.make_cfg3(3, 60), lambda: synth.make_cfg4(2, 2, 40, 10),
+               lambda: synth.as_backward(synth.make_cfg3(2, 50))):
+        w = H.with_time_varying_q(mk())
+        ob = H.oracle_batch(w)
+        fixed = H.oracle_batch(mk())
+        assert not np.array_equal(ob["P_MINUS"], fixed["P_MINUS"])
+        for c in (0, w.B - 1):
+            nd = H.numpy_chain(w, c)
+            for n in FWD:
+                assert H.rel_err(H.batch_chain(ob, n, c, w.m), nd[n]) <= 1e-9, (w.model, c, n)
+    # constant pages == fixed Q, bit for bit
+    w = synth.make_cfg4(2, 2, 40, 10)
+    w2 = H.with_time_varying_q(w)
+    w2.Q = np.ascontiguousarray(np.repeat(w.Q[None], w.T, axis=0))
+    a, b = H.oracle_batch(w), H.oracle_batch(w2)
+    for n in H.OUT_NAMES:
+        assert np.array_equal(a[n], b[n], equal_nan=True), n
+
+
 # ---------------------------------------------------------------- analytic KATs
 def test_kat_all_nan_observations():
     """(i) x all NaN => S_PLUS == S_MINUS, K = 0, innovations = 0 (GenericEKF.m:130-135)."""
