@@ -183,6 +183,8 @@ def main():
             sp = score_state["sp"]
             sp[0:3].copy_(runner.out["S_SMOOTH"][t_hist_idx, 0:3])
             sc = batch.score_sweep(runner.out["u_opt_smooth"], t_hist_idx + 1, sp, score_state["J0p"], score_state["J1p"])
+            # Pareto-front filter + optimum per region (TrainPredictPrescribeNPI.m:624-633), still on the device
+            score_state["front"] = batch.pareto_front(sc["J0"], sc["J1"], w.Sx)
             if world > 1:
                 batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
         elif world > 1:

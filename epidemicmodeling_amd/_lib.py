@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libepiekf.so")
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
-    "epi_calib_copy_f64_device",
+    "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_calib_copy_f64_device",
 ]
 
 
@@ -47,6 +47,11 @@ class Outputs(C.Structure):
 
 class SimDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "B", "K", "Su", "n_npi", "noise", "with_cost", "prefix_days")]
+
+
+class McDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "R", "n_scen", "K", "n_npi", "noise", "prefix_days")] + [
+        ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
 
 
 _lib = None
@@ -102,6 +107,10 @@ def lib():
         h.epi_seirp_sim_device.restype = C.c_int
         h.epi_seirp_sim_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+        h.epi_random_npi_mc_device.restype = C.c_int
+        h.epi_random_npi_mc_device.argtypes = [C.POINTER(McDesc)] + [C.c_void_p] * 8 + [C.c_void_p, C.c_char_p]
+        h.epi_pareto_front_device.restype = C.c_int
+        h.epi_pareto_front_device.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_void_p, C.c_char_p]
         h.epi_calib_copy_f64_device.restype = C.c_int
         h.epi_calib_copy_f64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p]
         if h.epi_abi_version() != 1:

@@ -188,6 +188,54 @@ def sialpha_sim(u, sp, z=None, u_series=None, with_cost=False, store=True, devic
     return out
 
 
+def random_npi_mc(sp, u_min, n_scen, K, seed=0, z=None, J0_prefix=None, J1_prefix=None, prefix_days=0,
+                  store_u=False, device="cuda:0"):
+    """Random-NPI Monte-Carlo scenarios (Tools/TrainPredictPrescribeNPI.m:496-521) on the device.
+
+    sp [48, R] per-region SIM_* rows (end-of-history state, model constants, SIM_U_MAX = NPI_MAXES, SIM_W = NPICost
+    weights), u_min [n_npi, R] = NPI_MINS, z [K, 3, n_scen*R] standard-normal draws or None; J0_prefix/J1_prefix [R]
+    sequential historic sums over prefix_days.  Returns dict J0, J1 [n_scen, R] (+ u [K, n_npi, n_scen*R])."""
+    dev = torch.device(device)
+    t = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else
+                                          torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev))
+    sp, u_min, z, J0p, J1p = t(sp), t(u_min), t(z), t(J0_prefix), t(J1_prefix)
+    n_npi, R = u_min.shape
+    d = _lib.McDesc()
+    d.abi_version, d.R, d.n_scen, d.K, d.n_npi = 1, R, int(n_scen), int(K), n_npi
+    d.noise, d.prefix_days = int(z is not None), int(prefix_days)
+    d.seed_lo, d.seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
+    out = {"J0": torch.empty((n_scen, R), dtype=torch.float64, device=dev),
+           "J1": torch.empty((n_scen, R), dtype=torch.float64, device=dev)}
+    if store_u:
+        out["u"] = torch.empty((K, n_npi, n_scen * R), dtype=torch.float64, device=dev)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_random_npi_mc_device(C.byref(d), _ptr(sp), _ptr(u_min), _ptr(z), _ptr(J0p), _ptr(J1p),
+                                             _ptr(out.get("u")), _ptr(out["J0"]), _ptr(out["J1"]),
+                                             C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return out
+
+
+def pareto_front(J0, J1, n_regions):
+    """Pareto-front filter and optimum of the sweep (Tools/TrainPredictPrescribeNPI.m:624-633) per region.
+    J0, J1: torch [B] in the sweep's chain order (region-major).  Returns (on_front bool [R, P], i_opt int [R],
+    0-based)."""
+    dev = J0.device
+    B = J0.numel()
+    P = B // n_regions
+    if P * n_regions != B:
+        raise ValueError("J0 does not hold the same number of points for every region")
+    on = torch.empty((n_regions, P), dtype=torch.int32, device=dev)
+    io = torch.empty((n_regions,), dtype=torch.int32, device=dev)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_pareto_front_device(n_regions, P, _ptr(J0.contiguous()), _ptr(J1.contiguous()), _ptr(on),
+                                            _ptr(io), C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return on.bool(), io
+
+
 def seirp_sim(par, init, dt, K, sat=None, integrator="euler", device="cuda:0"):
     """Batched SEIRP / SEIRPSaturatedResource.  par [K or 1, 7, B], init [5, B], sat [6, B] or None.
     Returns torch tensor [K, 5, B] (s,e,i,r,p rows; row 0 is the initial condition, SEIRP.m:20-24)."""

@@ -506,6 +506,48 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 // forward simulators
 // ---------------------------------------------------------------------------
 // Tools/SIalpha_Controlled.m:24-28 (+ NPICost.m:6-10 fused when J0/J1 are requested)
+struct SimPrm {
+    double alpha_min, alpha_max, gamma, b, beta, dt, s_std, i_std, a_std;
+    double ga[kNpi], um[kNpi], w[kNpi];   // gamma*a(k), u_max(k), NPICost weights(k)
+};
+// column `c` of an [EPI_SIM_PRM_COUNT][n] parameter block
+EPI_DEV void load_sim_prm(SimPrm &p, const double *__restrict__ sp, int n, int c, double &s, double &i, double &al)
+{
+    auto g = [&](int f) { return sp[(size_t)f * n + c]; };
+    s = g(EPI_SIM_S0); i = g(EPI_SIM_I0); al = g(EPI_SIM_ALPHA0);
+    p.alpha_min = g(EPI_SIM_ALPHA_MIN); p.alpha_max = g(EPI_SIM_ALPHA_MAX); p.gamma = g(EPI_SIM_GAMMA);
+    p.b = g(EPI_SIM_B); p.beta = g(EPI_SIM_BETA); p.dt = g(EPI_SIM_DT);
+    p.s_std = g(EPI_SIM_S_STD); p.i_std = g(EPI_SIM_I_STD); p.a_std = g(EPI_SIM_ALPHA_STD);
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) { p.ga[k] = p.gamma * g(EPI_SIM_A + k); p.um[k] = g(EPI_SIM_U_MAX + k); p.w[k] = g(EPI_SIM_W + k); }
+}
+// one day of SIalpha_Controlled.m:25-27 (entries of uk beyond n_npi are 0 and a(k) there is 0)
+EPI_DEV void sialpha_step(const SimPrm &p, const double (&uk)[kNpi], double z1, double z2, double z3, double &s, double &i,
+                          double &al)
+{
+    double dot = p.ga[0] * (p.um[0] - uk[0]);
+#pragma unroll
+    for (int k = 1; k < kNpi; k++) dot = fma(p.ga[k], p.um[k] - uk[k], dot);
+    const double sn = fmax(0.0, fmin(1.0, s - p.dt * (al * s * i + z1 * p.s_std)));
+    const double in = fmax(0.0, fmin(1.0, i + p.dt * (al * s * i - p.beta * i + z2 * p.i_std)));
+    const double an = fmax(p.alpha_min, fmin(p.alpha_max, al + p.dt * (-p.gamma * al + p.gamma * p.b + dot + z3 * p.a_std)));
+    s = sn; i = in; al = an;
+}
+// running sums of NPICost.m:6-10 over one more day: mean(newcases) and mean(weights(:).*inputs(:)) in column-major
+// order (NPI index fastest); `first` = this is the very first day of the span (sum starts with the term itself)
+EPI_DEV void npicost_accumulate(const SimPrm &p, const double (&uk)[kNpi], int n_npi, bool first, double s, double i, double al,
+                                double &acc0, double &acc1)
+{
+    const double nc = s * i * al;
+    acc0 = first ? nc : acc0 + nc;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++)
+        if (k < n_npi) {
+            const double term = p.w[k] * uk[k];
+            acc1 = (first && k == 0) ? term : acc1 + term;
+        }
+}
+
 __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const int32_t *__restrict__ u_series,
                                                    const double *__restrict__ u, const double *__restrict__ sp,
                                                    const double *__restrict__ z, double *__restrict__ so,
@@ -517,15 +559,10 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.B) return;
     const int B = d.B;
-    auto g = [&](int f) { return sp[(size_t)f * B + c]; };
     const int su = u_series ? u_series[c] : c;
-    double s = g(EPI_SIM_S0), i = g(EPI_SIM_I0), al = g(EPI_SIM_ALPHA0);
-    const double alpha_min = g(EPI_SIM_ALPHA_MIN), alpha_max = g(EPI_SIM_ALPHA_MAX), gamma = g(EPI_SIM_GAMMA);
-    const double b = g(EPI_SIM_B), beta = g(EPI_SIM_BETA), dt = g(EPI_SIM_DT);
-    const double s_std = g(EPI_SIM_S_STD), i_std = g(EPI_SIM_I_STD), a_std = g(EPI_SIM_ALPHA_STD);
-    double ga[kNpi], um[kNpi], w[kNpi];
-#pragma unroll
-    for (int k = 0; k < kNpi; k++) { ga[k] = gamma * g(EPI_SIM_A + k); um[k] = g(EPI_SIM_U_MAX + k); w[k] = g(EPI_SIM_W + k); }
+    SimPrm p;
+    double s, i, al;
+    load_sim_prm(p, sp, B, c, s, i, al);
     // NPICost over [historic days, simulated days] (TrainPredictPrescribeNPI.m:481-493): the historic part of
     // the two sequential sums arrives as a per-chain prefix and the simulated days are added in order
     const bool pre = (d.prefix_days > 0) && J0_prefix && J1_prefix;
@@ -534,31 +571,15 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
         double uk[kNpi];
 #pragma unroll
         for (int k = 0; k < kNpi; k++) uk[k] = (k < d.n_npi) ? u[((size_t)t * d.n_npi + k) * d.Su + su] : 0.0;
-        double dot = ga[0] * (um[0] - uk[0]);
-#pragma unroll
-        for (int k = 1; k < kNpi; k++) dot = fma(ga[k], um[k] - uk[k], dot);
         double z1 = 0.0, z2 = 0.0, z3 = 0.0;
         if (d.noise) {
             z1 = z[((size_t)t * 3 + 0) * B + c]; z2 = z[((size_t)t * 3 + 1) * B + c]; z3 = z[((size_t)t * 3 + 2) * B + c];
         }
-        const double sn = fmax(0.0, fmin(1.0, s - dt * (al * s * i + z1 * s_std)));
-        const double in = fmax(0.0, fmin(1.0, i + dt * (al * s * i - beta * i + z2 * i_std)));
-        const double an = fmax(alpha_min, fmin(alpha_max, al + dt * (-gamma * al + gamma * b + dot + z3 * a_std)));
-        s = sn; i = in; al = an;
+        sialpha_step(p, uk, z1, z2, z3, s, i, al);
         if (so) so[(size_t)t * B + c] = s;
         if (io) io[(size_t)t * B + c] = i;
         if (ao) ao[(size_t)t * B + c] = al;
-        if (d.with_cost) {
-            const double nc = s * i * al;
-            acc0 = (t == 0 && !pre) ? nc : acc0 + nc;
-            // mean(weights(:).*inputs(:)) in column-major order: NPI index fastest
-#pragma unroll
-            for (int k = 0; k < kNpi; k++)
-                if (k < d.n_npi) {
-                    const double term = w[k] * uk[k];
-                    acc1 = (t == 0 && k == 0 && !pre) ? term : acc1 + term;
-                }
-        }
+        if (d.with_cost) npicost_accumulate(p, uk, d.n_npi, t == 0 && !pre, s, i, al, acc0, acc1);
     }
     if (d.with_cost) {
         const size_t days = (size_t)d.K + (size_t)(pre ? d.prefix_days : 0);
@@ -566,6 +587,8 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
         if (J1) J1[c] = acc1 / (double)((size_t)d.n_npi * days);
     }
 }
+
+#include "scenario_kernels.hpp"
 
 struct SeirpRates { double ae, ai, kappa, rho, beta, mu, gamma; };
 EPI_DEV void seirp_rhs(const SeirpRates &r, const double (&y)[5], double (&f)[5])
@@ -1110,6 +1133,39 @@ int epi_sialpha_score_device(const epi_sim_desc *d, const int32_t *u_series, con
                              double *alpha, double *J0, double *J1, void *stream, char *err)
 {
     return sialpha_launch(d, u_series, u, sp, z, s, i, alpha, J0, J1, J0_prefix, J1_prefix, stream, err);
+}
+
+int epi_random_npi_mc_device(const epi_mc_desc *d, const double *sp, const double *u_min, const double *z,
+                             const double *J0_prefix, const double *J1_prefix, double *u_out, double *J0, double *J1,
+                             void *stream, char *err)
+{
+    if (!d || d->abi_version != EPIEKF_ABI_VERSION || d->R < 1 || d->n_scen < 1 || d->K < 1 || d->n_npi < 1 ||
+        d->n_npi > EPI_MAX_NPI || !sp || !u_min || !J0 || !J1 || (d->noise && !z) || d->prefix_days < 0 ||
+        (d->prefix_days > 0 && (!J0_prefix || !J1_prefix)) || (int64_t)d->R * d->n_scen > (int64_t)1 << 30) {
+        set_err(err, "bad Monte-Carlo scenario descriptor"); return EPI_ERR_BAD_ARG;
+    }
+    const int B = d->R * d->n_scen;
+    hipLaunchKernelGGL(random_npi_mc, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d, sp, u_min, z,
+                       J0_prefix, J1_prefix, u_out, J0, J1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "random_npi_mc launch");
+    return EPI_OK;
+}
+
+int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double *J1, int32_t *on_front,
+                            int32_t *i_opt, void *stream, char *err)
+{
+    if (R < 1 || P < 1 || !J0 || !J1 || (!on_front && !i_opt)) { set_err(err, "bad Pareto-front arguments"); return EPI_ERR_BAD_ARG; }
+    if (P > 8192) { set_err(err, "more than 8192 points per region"); return EPI_ERR_UNSUPPORTED; }
+    const size_t shmem = (size_t)2 * P * sizeof(double);
+    if (shmem > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute((const void *)pareto_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return hip_fail(err, e, "hipFuncSetAttribute");
+    }
+    hipLaunchKernelGGL(pareto_front, dim3(R), dim3(256), shmem, (hipStream_t)stream, P, J0, J1, on_front, i_opt);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "pareto_front launch");
+    return EPI_OK;
 }
 
 int epi_seirp_sim_device(int32_t B, int32_t K, int32_t par_steps, double dt, int32_t saturated, int32_t integrator,

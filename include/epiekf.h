@@ -198,6 +198,37 @@ int epi_sialpha_score_device(const epi_sim_desc *d, const int32_t *u_series, con
                              const double *z, const double *J0_prefix, const double *J1_prefix, double *s, double *i,
                              double *alpha, double *J0, double *J1, void *stream, char *err);
 
+/* Random-NPI Monte-Carlo scenarios of a region (Tools/TrainPredictPrescribeNPI.m:496-521): n_scen plans on the K
+ * forecast days with u(jj,t) = randi([NPI_MINS(jj), NPI_MAXES(jj)]) -- scenarios with 1-based index < n_scen/2 are
+ * constant over time (:502), the rest are redrawn every day -- each simulated with SIalpha_Controlled from the
+ * end-of-history state and scored with NPICost over [historic days, forecast days] (u = cat(2, IP, u), :515-517).
+ * Chain c = scenario * R + region.  sp [EPI_SIM_PRM_COUNT][R] per region (EPI_SIM_U_MAX rows are NPI_MAXES);
+ * u_min [n_npi][R] = NPI_MINS; z [K][3][n_scen*R] standard-normal draws when noise != 0, else NULL;
+ * J0_prefix/J1_prefix [R]: sequential sums over the prefix_days historic days (as for epi_sialpha_score_device;
+ * NULL when prefix_days == 0); u_out [K][n_npi][n_scen*R] or NULL; J0, J1 [n_scen][R].
+ * The integer draws come from Philox4x32-10 keyed by (seed_lo, seed_hi) with counter (region, scenario, NPI/4, day):
+ * reproducible on any launch geometry and by the CPU oracle; MATLAB's own randi stream is not reproduced. */
+typedef struct epi_mc_desc {
+    int32_t abi_version;
+    int32_t R;          /* regions */
+    int32_t n_scen;     /* scenarios per region (500 in the reference) */
+    int32_t K;          /* forecast days */
+    int32_t n_npi;
+    int32_t noise;
+    int32_t prefix_days;
+    uint32_t seed_lo, seed_hi;
+} epi_mc_desc;
+int epi_random_npi_mc_device(const epi_mc_desc *d, const double *sp, const double *u_min, const double *z,
+                             const double *J0_prefix, const double *J1_prefix, double *u_out, double *J0, double *J1,
+                             void *stream, char *err);
+
+/* Pareto-front filter and optimum of the sweep (Tools/TrainPredictPrescribeNPI.m:624-633), per region:
+ * on_front(ii) = (sum(J0 < J0(ii) & J1 < J1(ii)) == 0);  [~, I_opt] = min((J0/max(J0)).^2 + (J1/max(J1)).^2).
+ * J0, J1 [R][P] (region-major -- the chain order of the sweep); on_front [R][P] (0/1) or NULL; i_opt [R] 0-based or
+ * NULL.  P <= 8192 (the points of a region are staged in LDS). */
+int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double *J1, int32_t *on_front,
+                            int32_t *i_opt, void *stream, char *err);
+
 /* SEIRP.m:1-32 / SEIRPSaturatedResource.m:1-38 batched: par [K][7][B] per-step parameter arrays in the
  * order alpha_e, alpha_i, kappa, rho, beta, mu, gamma (or constant-in-time: par [1][7][B], par_steps=1);
  * init [5][B] = s0,e0,i0,r0,p0; out [K][5][B].  saturated != 0: sat [6][B] = beta_0,beta_s,mu_0,mu_s,

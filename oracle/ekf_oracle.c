@@ -901,3 +901,60 @@ int orc_ekf_run_batch(const orc_batch *bt, int n_threads)
     }
     return rc_all;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Scenario generation / selection around the sweep
+ * ---------------------------------------------------------------------------------------------- */
+/* Philox4x32-10, Salmon et al. SC'11 (Random123): the generator the HIP library draws NPI levels from. */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Tools/TrainPredictPrescribeNPI.m:499-511: the random plan of (region, scenario) on K forecast days,
+ * u n_npi x K column-major.  scenario is 0-based here; `scenario < runs/2` is on the 1-based index (:502). */
+void orc_random_npi_plan(uint32_t seed_lo, uint32_t seed_hi, int region, int scenario, int n_scen, int n_npi, int K,
+                         const double *npi_mins, const double *npi_maxes, double *u)
+{
+    const uint32_t key[2] = {seed_lo, seed_hi};
+    const int constant_plan = 2 * (scenario + 1) < n_scen;
+    for (int t = 0; t < K; t++) {
+        for (int k = 0; k < n_npi; k++) {
+            if (constant_plan && t > 0) { u[k + (size_t)n_npi * t] = u[k]; continue; }
+            const uint32_t ctr[4] = {(uint32_t)region, (uint32_t)scenario, (uint32_t)(k / 4),
+                                     constant_plan ? 0u : (uint32_t)t + 1u};
+            uint32_t x[4];
+            orc_philox4x32_10(ctr, key, x);
+            const double w = npi_maxes[k] - npi_mins[k];
+            const uint32_t span = (w >= 0.0 && w < 4294967295.0) ? (uint32_t)w + 1u : 1u;
+            /* randi([lo, hi]): lo + floor(U * span), U = x / 2^32 */
+            u[k + (size_t)n_npi * t] = npi_mins[k] + (double)(uint32_t)(((uint64_t)x[k % 4] * span) >> 32);
+        }
+    }
+}
+
+/* Tools/TrainPredictPrescribeNPI.m:624-633 for one region: is_on_pareto_front and I_opt (0-based). */
+void orc_pareto_front(int P, const double *J0, const double *J1, int *on_front, int *i_opt)
+{
+    double m0 = NAN, m1 = NAN; /* max() ignores NaN */
+    for (int q = 0; q < P; q++) { m0 = fmax(m0, J0[q]); m1 = fmax(m1, J1[q]); }
+    double best = NAN;
+    int bi = 0; /* min of an all-NaN vector returns index 1 */
+    for (int ii = 0; ii < P; ii++) {
+        int cnt = 0;
+        for (int o = 0; o < P; o++) cnt += (J0[o] < J0[ii]) && (J1[o] < J1[ii]);
+        if (on_front) on_front[ii] = (cnt == 0);
+        const double na = J0[ii] / m0, nb = J1[ii] / m1;
+        const double sc = na * na + nb * nb;
+        if (!isnan(sc) && (isnan(best) || sc < best)) { best = sc; bi = ii; }
+    }
+    if (i_opt) *i_opt = bi;
+}

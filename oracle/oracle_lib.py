@@ -230,3 +230,29 @@ def mrdivide(Bm, A):
     X = np.zeros((m, m), order="F")
     lib().orc_mrdivide(C.c_int(m), _dp(Bm), _dp(A), _dp(X))
     return X
+
+
+def philox4x32_10(ctr, key):
+    c = (C.c_uint32 * 4)(*[int(v) & 0xFFFFFFFF for v in ctr]); k = (C.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in key])
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def random_npi_plan(seed, region, scenario, n_scen, K, npi_mins, npi_maxes):
+    """n_npi x K plan of (region, scenario) as the HIP library draws it (TrainPredictPrescribeNPI.m:499-511)."""
+    lo = np.ascontiguousarray(npi_mins, dtype=np.float64); hi = np.ascontiguousarray(npi_maxes, dtype=np.float64)
+    n = lo.shape[0]
+    u = np.zeros((n, K), order="F")
+    lib().orc_random_npi_plan(C.c_uint32(int(seed) & 0xFFFFFFFF), C.c_uint32((int(seed) >> 32) & 0xFFFFFFFF),
+                              C.c_int(region), C.c_int(scenario), C.c_int(n_scen), C.c_int(n), C.c_int(K),
+                              _dp(lo), _dp(hi), _dp(u))
+    return u
+
+
+def pareto_front(J0, J1):
+    """(is_on_pareto_front bool [P], I_opt 0-based) of one region, TrainPredictPrescribeNPI.m:624-633."""
+    a = np.ascontiguousarray(J0, dtype=np.float64); b = np.ascontiguousarray(J1, dtype=np.float64)
+    on = np.zeros(a.shape[0], dtype=np.int32); io = C.c_int(0)
+    lib().orc_pareto_front(C.c_int(a.shape[0]), _dp(a), _dp(b), on.ctypes.data_as(C.POINTER(C.c_int)), C.byref(io))
+    return on.astype(bool), io.value
