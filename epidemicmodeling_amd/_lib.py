@@ -16,6 +16,7 @@ ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_calib_copy_f64_device",
+    "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
 ]
 
 
@@ -52,6 +53,17 @@ class SimDesc(C.Structure):
 class McDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "R", "n_scen", "K", "n_npi", "noise", "prefix_days")] + [
         ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
+
+
+class RtDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "B", "T", "Sx", "L", "order")]
+
+
+RT_OUT_NAMES = ("S_MINUS", "S_PLUS", "P_MINUS", "P_PLUS", "K_GAIN", "S_SMOOTH", "P_SMOOTH", "innovations", "rho")
+
+
+class RtOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in RT_OUT_NAMES]
 
 
 _lib = None
@@ -111,6 +123,14 @@ def lib():
         h.epi_random_npi_mc_device.argtypes = [C.POINTER(McDesc)] + [C.c_void_p] * 8 + [C.c_void_p, C.c_char_p]
         h.epi_pareto_front_device.restype = C.c_int
         h.epi_pareto_front_device.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 4 + [C.c_void_p, C.c_char_p]
+        h.epi_rt_expfit_validate.restype = C.c_int
+        h.epi_rt_expfit_validate.argtypes = [C.POINTER(RtDesc), C.c_char_p]
+        h.epi_rt_expfit_run_device.restype = C.c_int
+        h.epi_rt_expfit_run_device.argtypes = [C.POINTER(RtDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RtOutputs),
+                                               C.c_void_p, C.c_char_p]
+        h.epi_rt_expfit_run_host.restype = C.c_int
+        h.epi_rt_expfit_run_host.argtypes = [C.POINTER(RtDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RtOutputs),
+                                             C.c_int, C.c_char_p]
         h.epi_calib_copy_f64_device.restype = C.c_int
         h.epi_calib_copy_f64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p]
         if h.epi_abi_version() != 1:

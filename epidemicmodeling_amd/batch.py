@@ -236,6 +236,51 @@ def pareto_front(J0, J1, n_regions):
     return on.bool(), io
 
 
+RT_OUT_ROWS = {"S_MINUS": 2, "S_PLUS": 2, "P_MINUS": 4, "P_PLUS": 4, "K_GAIN": 2, "S_SMOOTH": 2, "P_SMOOTH": 4,
+               "innovations": 0, "rho": 0}
+
+
+class RtRunner:
+    """Batched Tools/Rt_ExpFitEKF.m on the device: inputs of a synth.RtWorkload resident in HBM, outputs
+    pre-allocated; run() only enqueues rt_expfit_fwd (+ rt_expfit_bwd when a smoothed output is selected)."""
+
+    def __init__(self, w, device="cuda:0", outputs=None):
+        self.device = dev = torch.device(device)
+        f = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev)
+        self.x, self.rp = f(w.x), f(w.rp)
+        self.x_series = None if w.x_series is None else torch.as_tensor(np.ascontiguousarray(w.x_series), dtype=torch.int32).to(dev)
+        self.T, self.B = w.T, w.B
+        names = list(_lib.RT_OUT_NAMES) if outputs is None else list(outputs)
+        for n in ("S_MINUS", "S_PLUS", "P_MINUS", "P_PLUS"):      # the smoother reads them back
+            if n not in names:
+                names.append(n)
+        self.out = {n: torch.empty((w.T, w.B) if RT_OUT_ROWS[n] == 0 else (w.T, RT_OUT_ROWS[n], w.B), dtype=torch.float64,
+                                   device=dev) for n in names}
+        self.desc = _lib.RtDesc()
+        self.desc.abi_version, self.desc.B, self.desc.T, self.desc.Sx = 1, w.B, w.T, w.x.shape[1]
+        self.desc.L, self.desc.order = int(w.L), int(w.order)
+        self.outs = _lib.RtOutputs()
+        for n in _lib.RT_OUT_NAMES:
+            setattr(self.outs, n, _ptr(self.out.get(n)))
+        self.err = C.create_string_buffer(256)
+        _lib.check(_lib.lib().epi_rt_expfit_validate(C.byref(self.desc), self.err), self.err)
+
+    def run(self, stream=None):
+        st = torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = _lib.lib().epi_rt_expfit_run_device(C.byref(self.desc), _ptr(self.x_series), _ptr(self.x), _ptr(self.rp),
+                                                 C.byref(self.outs), C.c_void_p(st.cuda_stream), self.err)
+        _lib.check(rc, self.err)
+        return self.out
+
+
+def rt_expfit(w, device="cuda:0", outputs=None):
+    """Convenience: upload a synth.RtWorkload, run once, return dict name -> numpy array."""
+    r = RtRunner(w, device, outputs)
+    r.run()
+    torch.cuda.synchronize(r.device)
+    return {n: t.cpu().numpy() for n, t in r.out.items()}
+
+
 def seirp_sim(par, init, dt, K, sat=None, integrator="euler", device="cuda:0"):
     """Batched SEIRP / SEIRPSaturatedResource.  par [K or 1, 7, B], init [5, B], sat [6, B] or None.
     Returns torch tensor [K, 5, B] (s,e,i,r,p rows; row 0 is the initial condition, SEIRP.m:20-24)."""

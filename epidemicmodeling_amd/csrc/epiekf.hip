@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
 }
 
 #include "scenario_kernels.hpp"
+#include "rt_expfit.hpp"
 
 struct SeirpRates { double ae, ai, kappa, rho, beta, mu, gamma; };
 EPI_DEV void seirp_rhs(const SeirpRates &r, const double (&y)[5], double (&f)[5])
@@ -1165,6 +1166,90 @@ int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double
     hipLaunchKernelGGL(pareto_front, dim3(R), dim3(256), shmem, (hipStream_t)stream, P, J0, J1, on_front, i_opt);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(err, e, "pareto_front launch");
+    return EPI_OK;
+}
+
+int epi_rt_expfit_validate(const epi_rt_desc *d, char *err)
+{
+    if (!d) { set_err(err, "NULL descriptor"); return EPI_ERR_BAD_ARG; }
+    if (d->abi_version != EPIEKF_ABI_VERSION) { set_err(err, "ABI version mismatch"); return EPI_ERR_BAD_ARG; }
+    if (d->B < 1 || d->T < 1 || d->Sx < 1 || d->L < 1) { set_err(err, "B, T, Sx, L must be >= 1"); return EPI_ERR_BAD_ARG; }
+    if (d->B > (1 << 23) || d->Sx > (1 << 23)) { set_err(err, "B, Sx are limited to 2^23"); return EPI_ERR_BAD_ARG; }
+    if (d->order != 1 && d->order != 2) { set_err(err, epi_status_string(EPI_ERR_UNDEFINED_ORDER)); return EPI_ERR_UNDEFINED_ORDER; }
+    if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
+    return EPI_OK;
+}
+
+int epi_rt_expfit_run_device(const epi_rt_desc *d, const int32_t *x_series, const double *x, const double *rp,
+                             const epi_rt_outputs *out, void *stream, char *err)
+{
+    int rc = epi_rt_expfit_validate(d, err);
+    if (rc != EPI_OK) return rc;
+    if (!x || !rp || !out) { set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG; }
+    if (!x_series && d->Sx != d->B) { set_err(err, "identity x_series needs Sx == B"); return EPI_ERR_BAD_ARG; }
+    if (!out->S_MINUS || !out->S_PLUS || !out->P_MINUS || !out->P_PLUS) {
+        set_err(err, "S_MINUS, S_PLUS, P_MINUS, P_PLUS are required outputs"); return EPI_ERR_BAD_ARG;
+    }
+    RtArgs a{};
+    a.B = d->B; a.T = d->T; a.Sx = d->Sx; a.L = d->L; a.order = d->order;
+    a.x_series = x_series; a.x = x; a.rp = rp;
+    a.S_MINUS = out->S_MINUS; a.S_PLUS = out->S_PLUS; a.P_MINUS = out->P_MINUS; a.P_PLUS = out->P_PLUS;
+    a.K_GAIN = out->K_GAIN; a.S_SMOOTH = out->S_SMOOTH; a.P_SMOOTH = out->P_SMOOTH;
+    a.innovations = out->innovations; a.rho = out->rho;
+    const size_t shmem = (size_t)3 * d->L * kWave * sizeof(double);
+    hipError_t e;
+    if (shmem > 64u * 1024u &&
+        (e = hipFuncSetAttribute((const void *)rt_expfit_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)) != hipSuccess)
+        return hip_fail(err, e, "hipFuncSetAttribute");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rt_expfit_fwd, dim3((d->B + kWave - 1) / kWave), dim3(kWave), shmem, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "rt_expfit_fwd launch");
+    if (a.S_SMOOTH || a.P_SMOOTH) {
+        hipLaunchKernelGGL(rt_expfit_bwd, dim3((d->B + 255) / 256), dim3(256), 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "rt_expfit_bwd launch");
+    }
+    return EPI_OK;
+}
+
+int epi_rt_expfit_run_host(const epi_rt_desc *d, const int32_t *x_series, const double *x, const double *rp,
+                           const epi_rt_outputs *out, int device, char *err)
+{
+    int rc = epi_rt_expfit_validate(d, err);
+    if (rc != EPI_OK) return rc;
+    if (!x || !rp || !out) { set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    const size_t B = d->B, T = d->T;
+    std::vector<void *> allocs;
+    auto fail = [&](hipError_t ee, const char *what) { for (void *p : allocs) (void)hipFree(p); return hip_fail(err, ee, what); };
+    auto dev_alloc = [&](size_t bytes, void **p) -> hipError_t {
+        hipError_t ee = hipMalloc(p, bytes);
+        if (ee == hipSuccess) allocs.push_back(*p);
+        return ee;
+    };
+    void *dxs = nullptr, *dx = nullptr, *drp = nullptr;
+    if (x_series) {
+        if ((e = dev_alloc(B * 4, &dxs)) != hipSuccess || (e = hipMemcpy(dxs, x_series, B * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload x_series");
+    }
+    if ((e = dev_alloc(T * d->Sx * 8, &dx)) != hipSuccess || (e = hipMemcpy(dx, x, T * d->Sx * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload x");
+    if ((e = dev_alloc((size_t)EPI_RT_PRM_COUNT * B * 8, &drp)) != hipSuccess || (e = hipMemcpy(drp, rp, (size_t)EPI_RT_PRM_COUNT * B * 8, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "upload rp");
+    struct O { double *host; double **dev; size_t bytes; bool required; };
+    epi_rt_outputs dout{};
+    const size_t n2 = T * 2 * B * 8, n4 = T * 4 * B * 8, n1 = T * B * 8;
+    O outs[] = {{out->S_MINUS, &dout.S_MINUS, n2, true}, {out->S_PLUS, &dout.S_PLUS, n2, true}, {out->P_MINUS, &dout.P_MINUS, n4, true},
+                {out->P_PLUS, &dout.P_PLUS, n4, true}, {out->K_GAIN, &dout.K_GAIN, n2, false}, {out->S_SMOOTH, &dout.S_SMOOTH, n2, false},
+                {out->P_SMOOTH, &dout.P_SMOOTH, n4, false}, {out->innovations, &dout.innovations, n1, false}, {out->rho, &dout.rho, n1, false}};
+    for (auto &o : outs)
+        if (o.host || o.required) {   // forward quantities the caller does not want still feed the smoother
+            void *p; if ((e = dev_alloc(o.bytes, &p)) != hipSuccess) return fail(e, "hipMalloc output");
+            *o.dev = (double *)p;
+        }
+    rc = epi_rt_expfit_run_device(d, (const int32_t *)dxs, (const double *)dx, (const double *)drp, &dout, nullptr, err);
+    if (rc != EPI_OK) { for (void *p : allocs) (void)hipFree(p); return rc; }
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "kernel execution");
+    for (auto &o : outs)
+        if (o.host && (e = hipMemcpy(o.host, *o.dev, o.bytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
+    for (void *p : allocs) (void)hipFree(p);
     return EPI_OK;
 }
 

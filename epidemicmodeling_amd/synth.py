@@ -463,3 +463,63 @@ def make_mask_ensemble(n_regions: int = 8, T: int = 200, num_forecast_days: int 
                     s_final=np.full((3, B), np.nan), Ps_final=np.full((9, B), np.nan),
                     Q=np.ascontiguousarray(base.Q[:, rr]),
                     meta={"workload": "mask_ensemble", "regions": n_regions, "num_forecast_days": num_forecast_days})
+
+
+# ---------------------------------------------------------------------------
+# Rt_ExpFitEKF workloads (Tools/Rt_ExpFitEKF.m; testScripts/test04FullFeatureExtMLpipeline.m:198-219)
+# ---------------------------------------------------------------------------
+RT_PRM_COUNT = 19
+RT_ROWS = {"time_scale": 0, "alpha": 1, "sigma": 2, "w_bar": 3, "v_bar": 5, "R_v": 6, "beta": 7, "gamma": 8,
+           "s_init": 9, "Ps_init": 11, "Q_w": 15}
+
+
+@dataclass
+class RtWorkload:
+    """Batched Rt_ExpFitEKF problem: x [T, Sx] smoothed new-case counts, rp [19, B] (EPI_RT_* rows)."""
+    x: np.ndarray
+    rp: np.ndarray
+    x_series: np.ndarray | None
+    L: int = 21
+    order: int = 1
+
+    @property
+    def T(self) -> int:
+        return self.x.shape[0]
+
+    @property
+    def B(self) -> int:
+        return self.rp.shape[1]
+
+
+def make_rt(n_regions=40, T=300, n_draws=1, order=1, horizon=0, seed=0, w_bar=(0.0, 0.0), L=21):
+    """Smoothed daily new-case curves (piecewise exponential growth/decay, counts 1e2..1e5) with the caller's
+    constants of test04FullFeatureExtMLpipeline.m:203-216; the last `horizon` days are NaN (forecast).  n_draws > 1
+    replicates every region with jittered noise settings (a Monte-Carlo over the filter's tuning)."""
+    rng = np.random.default_rng(seed)
+    lam = np.zeros((T, n_regions))
+    for r in range(n_regions):
+        t0 = 0
+        while t0 < T:
+            seg = int(rng.integers(20, 70))
+            lam[t0:t0 + seg, r] = rng.uniform(-0.06, 0.08)
+            t0 += seg
+    lam = np.apply_along_axis(lambda v: np.convolve(np.pad(v, 7, mode="edge"), np.ones(15) / 15, mode="valid"), 0, lam)
+    x0 = 10.0 ** rng.uniform(2, 3.5, n_regions)
+    x = x0[None, :] * np.exp(np.clip(np.cumsum(lam, axis=0), -4.0, 6.0))
+    x = x * (1 + 0.03 * rng.standard_normal(x.shape))
+    x = np.maximum(x, 1.0)
+    if horizon > 0:
+        x[T - horizon:] = np.nan
+    B = n_regions * n_draws
+    rr = np.repeat(np.arange(n_regions), n_draws)
+    rp = np.zeros((RT_PRM_COUNT, B))
+    jit = (lambda s: 1.0 + s * rng.standard_normal(B)) if n_draws > 1 else (lambda s: np.ones(B))
+    rp[0] = 1.0; rp[1] = 0.9; rp[2] = 0.1                       # time_scale, lambda forgetting factor, sigma
+    rp[3], rp[4] = w_bar
+    rp[5] = 0.0; rp[6] = 100.0 * jit(0.1) ** 2; rp[7] = 0.9; rp[8] = 0.995
+    rp[9] = x[0, rr]; rp[10] = lam[0, rr]
+    q1, q2 = (250.0 * jit(0.1)) ** 2, (3.0e-3 * jit(0.1)) ** 2
+    rp[15], rp[18] = q1, q2
+    rp[11], rp[14] = 100 * q1, 100 * q2
+    return RtWorkload(x=np.ascontiguousarray(x), rp=rp, x_series=rr.astype(np.int32) if n_draws > 1 else None, L=L,
+                      order=order)

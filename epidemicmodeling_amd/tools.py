@@ -231,3 +231,44 @@ def NewCaseEKFEstimatorWithOptimalNPI_codegen(u, x, params, s_init, Ps_init, s_f
              v_bar, Q_w, R_v, beta, gamma, inv_monitor_len, order)
     return (r["u_opt"], r["S_MINUS"], r["S_PLUS"], r["P_MINUS"], r["P_PLUS"], r["K_GAIN"], r["S_SMOOTH"],
             r["P_SMOOTH"], r["innovations"], r["rho"])
+
+
+def Rt_ExpFitEKF(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma, inv_monitor_len, order, device=0):
+    """[S_MINUS, S_PLUS, P_MINUS, P_PLUS, K_GAIN, S_SMOOTH, P_SMOOTH, innovations, rho] = Rt_ExpFitEKF(...)
+    -- Tools/Rt_ExpFitEKF.m:1 (exponential-fit EKF/EKS over the new-case counts; order 2 adds the Hessian terms).
+    x is 1 x T; params = [time_scale, alpha, sigma]."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 2 and x.shape[0] != 1:
+        raise ValueError("this engine implements the scalar-observation filter: size(x,1) must be 1")
+    x = np.ascontiguousarray(x.reshape(-1, 1))
+    T = x.shape[0]
+    s_init = np.asarray(s_init, dtype=np.float64).reshape(-1)
+    params = np.asarray(params, dtype=np.float64).reshape(-1)
+    w_bar = np.asarray(w_bar, dtype=np.float64).reshape(-1)
+    if s_init.shape[0] != 2 or w_bar.shape[0] < 2:
+        raise ValueError("Rt_ExpFitEKF: s_init and w_bar must have 2 elements")
+    if params.shape[0] < 3:
+        raise IndexError("Index exceeds the number of array elements.")      # params(3), Rt_ExpFitEKF.m:136
+    rp = np.zeros((19, 1))
+    rp[0:3, 0] = params[:3]; rp[3:5, 0] = w_bar[:2]
+    rp[5] = float(np.asarray(v_bar).reshape(-1)[0]); rp[6] = float(np.asarray(R_v).reshape(-1)[0])
+    rp[7], rp[8] = float(beta), float(gamma)
+    rp[9:11, 0] = s_init
+    rp[11:15, 0] = np.asarray(Ps_init, dtype=np.float64).reshape(2, 2).reshape(-1, order="F")
+    rp[15:19, 0] = np.asarray(Q_w, dtype=np.float64).reshape(2, 2).reshape(-1, order="F")
+    d = _lib.RtDesc()
+    d.abi_version, d.B, d.T, d.Sx, d.L, d.order = 1, 1, T, 1, int(inv_monitor_len), int(order)
+    rows = {"S_MINUS": 2, "S_PLUS": 2, "P_MINUS": 4, "P_PLUS": 4, "K_GAIN": 2, "S_SMOOTH": 2, "P_SMOOTH": 4,
+            "innovations": 1, "rho": 1}
+    out = {n: np.zeros((T, r, 1)) for n, r in rows.items()}
+    outs = _lib.RtOutputs()
+    for n in rows:
+        setattr(outs, n, out[n].ctypes.data)
+    err = C.create_string_buffer(256)
+    rc = _lib.lib().epi_rt_expfit_run_host(C.byref(d), None, x.ctypes.data, rp.ctypes.data, C.byref(outs), int(device), err)
+    _lib.check(rc, err)
+    S = lambda n: np.asfortranarray(out[n][:, :, 0].T)
+    P = lambda n: np.asfortranarray(out[n][:, :, 0].reshape(T, 2, 2).transpose(2, 1, 0))
+    return (S("S_MINUS"), S("S_PLUS"), P("P_MINUS"), P("P_PLUS"), np.asfortranarray(out["K_GAIN"][:, :, 0].T.reshape(2, 1, T)),
+            S("S_SMOOTH"), P("P_SMOOTH"), out["innovations"][:, 0, 0].reshape(1, T).copy(),
+            out["rho"][:, 0, 0].reshape(T, 1).copy())          # squeeze(rho): T x 1

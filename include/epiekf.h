@@ -229,6 +229,41 @@ int epi_random_npi_mc_device(const epi_mc_desc *d, const double *sp, const doubl
 int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double *J1, int32_t *on_front,
                             int32_t *i_opt, void *stream, char *err);
 
+/* ---- Tools/Rt_ExpFitEKF.m:1 -- 2-state exponential-fit EKF/EKS over the new-case counts, order 1 or 2 ----
+ * [S_MINUS, S_PLUS, P_MINUS, P_PLUS, K_GAIN, S_SMOOTH, P_SMOOTH, innovations, rho] =
+ *     Rt_ExpFitEKF(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma, inv_monitor_len, order)
+ * batched over B chains: x [T][Sx] (NaN = missing/forecast day), x_series [B] or NULL (identity, Sx == B),
+ * rp [EPI_RT_PRM_COUNT][B] holding every other argument of the signature per chain.  Outputs [T][2][B] (S_*, K_GAIN),
+ * [T][4][B] (P_*, column-major 2 x 2), [T][B] (innovations, rho).  S_MINUS, S_PLUS, P_MINUS, P_PLUS are required
+ * (the smoother reads them back); the others may be NULL.  `order` other than 1 or 2 returns
+ * EPI_ERR_UNDEFINED_ORDER ('Undefined order', Rt_ExpFitEKF.m:46,77).  exp/tanh come from the device math library:
+ * results agree with a libm evaluation to rounding level, not bit for bit. */
+enum {
+    EPI_RT_TIME_SCALE = 0, EPI_RT_ALPHA = 1, EPI_RT_SIGMA = 2,   /* params(1:3) */
+    EPI_RT_W_BAR = 3,      /* w_bar(1:2) */
+    EPI_RT_V_BAR = 5, EPI_RT_R_V = 6, EPI_RT_BETA_EKF = 7, EPI_RT_GAMMA_EKF = 8,
+    EPI_RT_S_INIT = 9,     /* s_init(1:2) */
+    EPI_RT_PS_INIT = 11,   /* Ps_init(:), column-major */
+    EPI_RT_Q_W = 15,       /* Q_w(:), column-major */
+    EPI_RT_PRM_COUNT = 19
+};
+typedef struct epi_rt_desc {
+    int32_t abi_version;
+    int32_t B, T, Sx;
+    int32_t L;       /* inv_monitor_len, 1..106 */
+    int32_t order;   /* 1 or 2 */
+} epi_rt_desc;
+typedef struct epi_rt_outputs {
+    double *S_MINUS, *S_PLUS, *P_MINUS, *P_PLUS, *K_GAIN, *S_SMOOTH, *P_SMOOTH, *innovations, *rho;
+} epi_rt_outputs;
+int epi_rt_expfit_validate(const epi_rt_desc *d, char *err);
+/* device pointers, enqueues on `stream` */
+int epi_rt_expfit_run_device(const epi_rt_desc *d, const int32_t *x_series, const double *x, const double *rp,
+                             const epi_rt_outputs *out, void *stream, char *err);
+/* host pointers (what a MEX gateway calls): uploads, runs, downloads, synchronises */
+int epi_rt_expfit_run_host(const epi_rt_desc *d, const int32_t *x_series, const double *x, const double *rp,
+                           const epi_rt_outputs *out, int device, char *err);
+
 /* SEIRP.m:1-32 / SEIRPSaturatedResource.m:1-38 batched: par [K][7][B] per-step parameter arrays in the
  * order alpha_e, alpha_i, kappa, rho, beta, mu, gamma (or constant-in-time: par [1][7][B], par_steps=1);
  * init [5][B] = s0,e0,i0,r0,p0; out [K][5][B].  saturated != 0: sat [6][B] = beta_0,beta_s,mu_0,mu_s,

@@ -2,13 +2,7 @@ function [u_opt, u_opt_smooth, S_MINUS, S_PLUS, S_SMOOTH, P_MINUS, P_PLUS, P_SMO
 % Drop-in replacement of the reference's Tools/SIAlphaModelBackwardEKF.m (same signature, same outputs): put this
 % directory before the reference's Tools/ on the MATLAB path.  Runs on an MI355X through epiekf_mex.
 m = length(s_init);
-if isscalar(Q_w), Q_w = Q_w * eye(m); end
-if ~isequal(size(Q_w), [m m])
-    if ndims(Q_w) == 3 || (isvector(Q_w) && length(Q_w) == size(x, 2))
-        error('epiekf:unsupported', 'time-varying Q_w is not supported by the MI355X engine');
-    end
-    error('Process noise covariance noise mismatch');
-end
+Q_w = epiekf_expand_Q(Q_w, m, size(x, 2));   % m x m, or m x m x T for a time-varying Q_w (GenericEKF.m:63-76)
 if isequal(params.obs_type, 'NEWCASES'), ot = 0; elseif isequal(params.obs_type, 'TOTALCASES'), ot = 1; else, error('unknown observation type'); end
 prm = epiekf_pack_params(params, size(u, 1), v_bar, beta, gamma, 2);
 o = epiekf_mex(2, u, x, prm, s_init(:), Ps_init, s_final(:), Ps_final, Q_w, R_v, inv_monitor_len, order, ot);

@@ -38,6 +38,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     if (nR == 1) d.r_mode = 0;                                   // scalar R_v: fixed_R = true  (GenericEKF.m:79-81)
     else if (nR == T && (mxGetM(Rv) == 1 || mxGetN(Rv) == 1)) d.r_mode = 1;   // 1 x T vector (:82-85)
     else mexErrMsgTxt("Observation noise covariance noise mismatch");
+    // Q_w: m x m, or m x m x T (time-varying; column-major pages == the ABI's [T][m*m][1])
+    const mwSize nQ = mxGetNumberOfElements(prhs[8]);
+    if (nQ == (mwSize)(m * m)) d.q_mode = 0;
+    else if (nQ == (mwSize)(m * m) * T) d.q_mode = 1;
+    else mexErrMsgTxt("Process noise covariance noise mismatch");
     const bool has_uos = (model <= EPI_MODEL_SIA6_BWD);
     d.out_mask = EPI_OUT_ALL & ~(has_uos ? 0u : (unsigned)EPI_OUT_U_OPT_SMOOTH);
 

@@ -486,3 +486,76 @@ def npi_cost(newcases, inputs, weights):
     J0 = float(np.mean(np.asarray(newcases, dtype=np.float64)))
     wi = np.asarray(weights, dtype=np.float64) * np.asarray(inputs, dtype=np.float64)
     return J0, float(np.mean(wi.reshape(-1, order="F")))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Tools/Rt_ExpFitEKF.m -- second, independent reading (NumPy/LAPACK) used to cross-check the C oracle
+# ---------------------------------------------------------------------------------------------------
+def rt_expfit_ekf(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma, inv_monitor_len, order):
+    """[S_MINUS, S_PLUS, P_MINUS, P_PLUS, K_GAIN, S_SMOOTH, P_SMOOTH, innovations, rho] = Rt_ExpFitEKF(...)
+    for a scalar observation series x (1 x T).  Tools/Rt_ExpFitEKF.m:1-130."""
+    if order not in (1, 2):
+        raise ValueError("Undefined order")                       # :46, :77
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    T, m, Lw = x.shape[0], 2, int(inv_monitor_len)
+    ts, alpha, sigma = (float(v) for v in params)
+    w_bar = np.asarray(w_bar, dtype=np.float64).reshape(-1)
+    Q = np.asarray(Q_w, dtype=np.float64); R = float(R_v)
+    S_MINUS = np.zeros((m, T)); S_PLUS = np.zeros((m, T)); P_MINUS = np.zeros((m, m, T)); P_PLUS = np.zeros((m, m, T))
+    K_GAIN = np.zeros((m, 1, T)); innovations = np.zeros((1, T)); rho = np.zeros(T)
+    win_mean = np.zeros(Lw); win_cov = np.zeros(Lw); win_covn = np.zeros(Lw)
+    sk_minus = np.asarray(s_init, dtype=np.float64).reshape(-1).copy(); Pk_minus = np.asarray(Ps_init, dtype=np.float64).copy()
+    C = np.array([[1.0, 0.0]]); D = 1.0
+
+    def jac(s):                                                   # :143-160
+        tnh = np.tanh((alpha * s[1] + w_bar[1]) / sigma)
+        e = np.exp(ts * s[1])
+        A = np.array([[e, ts * s[0] * e], [0.0, alpha * (1 - tnh ** 2)]])
+        B = np.array([[1.0, 0.0], [0.0, 1 - tnh ** 2]])
+        return A, B, tnh, e
+
+    def hess(s, Pk, Qk):                                          # :163-199
+        _, _, tnh, e = jac(s)
+        Fs = [np.array([[0.0, ts * e], [ts * e, ts ** 2 * s[0] * e]]),
+              np.array([[0.0, 0.0], [0.0, -2 * alpha ** 2 / sigma * tnh * (1 - tnh ** 2)]])]
+        Fw = [np.zeros((2, 2)), np.array([[0.0, 0.0], [0.0, -2 / sigma * tnh * (1 - tnh ** 2)]])]
+        fs = np.array([np.trace(Pk @ Fs[i]) / 2 for i in range(2)])
+        Cs = np.array([[np.trace(Pk @ Fs[i] @ Pk @ Fs[j]) / 2 for j in range(2)] for i in range(2)])
+        fw = np.array([np.trace(Qk @ Fw[i]) / 2 for i in range(2)])
+        Cw = np.array([[np.trace(Qk @ Fw[i] @ Qk @ Fw[j]) / 2 for j in range(2)] for i in range(2)])
+        return fs, Cs, fw, Cw
+
+    for k in range(T):
+        S_MINUS[:, k] = sk_minus; P_MINUS[:, :, k] = Pk_minus
+        xk_minus = sk_minus[0] + v_bar                            # obs Hessian terms are identically zero (:202-227)
+        if not np.isnan(x[k]):
+            innov = x[k] - xk_minus
+            Kg = Pk_minus @ C.T / (C @ Pk_minus @ C.T + gamma * (D * R * D))
+            Pk_plus = (np.eye(m) - Kg @ C) @ Pk_minus / gamma
+            sk_plus = sk_minus + (Kg * innov).reshape(-1)
+        else:
+            innov = 0.0; Kg = np.zeros((m, 1)); Pk_plus = Pk_minus.copy(); sk_plus = sk_minus.copy()
+        A, B, tnh, e = jac(sk_plus)
+        if order == 2:
+            fs, Fsp, fw, Fwp = hess(sk_plus, Pk_plus, Q)
+        else:
+            fs = fw = np.zeros(m); Fsp = Fwp = np.zeros((m, m))
+        sk_minus = np.array([sk_plus[0] * e + w_bar[0], sigma * tnh]) + fs + fw
+        Pk_minus = A @ Pk_plus @ A.T + B @ Q @ B.T + Fsp + Fwp
+        S_PLUS[:, k] = sk_plus; P_PLUS[:, :, k] = Pk_plus; K_GAIN[:, :, k] = Kg; innovations[0, k] = innov
+        cnt = min(k + 1, Lw)
+        win_mean = np.concatenate(([innov], win_mean[:-1]))
+        mu = win_mean.sum() / cnt
+        cc = (innov - mu) ** 2
+        win_cov = np.concatenate(([cc], win_cov[:-1])); win_covn = np.concatenate(([cc / R], win_covn[:-1]))
+        rho[k] = win_covn.sum() / cnt
+        if beta != 1 and not np.isnan(x[k]):
+            R = beta * R + (1 - beta) * win_cov.sum() / cnt
+    S_SMOOTH = np.zeros_like(S_PLUS); P_SMOOTH = np.zeros_like(P_PLUS)
+    S_SMOOTH[:, -1] = S_PLUS[:, -1]; P_SMOOTH[:, :, -1] = P_PLUS[:, :, -1]
+    for k in range(T - 2, -1, -1):
+        A = jac(S_PLUS[:, k])[0]
+        J = np.linalg.solve(P_MINUS[:, :, k + 1].T, (P_PLUS[:, :, k] @ A.T).T).T       # mrdivide
+        S_SMOOTH[:, k] = S_PLUS[:, k] + J @ (S_SMOOTH[:, k + 1] - S_MINUS[:, k + 1])
+        P_SMOOTH[:, :, k] = P_PLUS[:, :, k] - J @ (P_MINUS[:, :, k + 1] - P_SMOOTH[:, :, k + 1]) @ J.T
+    return S_MINUS, S_PLUS, P_MINUS, P_PLUS, K_GAIN, S_SMOOTH, P_SMOOTH, innovations, rho

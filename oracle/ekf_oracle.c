@@ -958,3 +958,189 @@ void orc_pareto_front(int P, const double *J0, const double *J1, int *on_front, 
     }
     if (i_opt) *i_opt = bi;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Tools/Rt_ExpFitEKF.m:1-227 -- 2-state exponential-fit EKF/EKS with second-order (Hessian) terms
+ * (SURVEY.md 8(f3)).  exp / tanh are libm's; the HIP kernels use the device math library, so parity
+ * for this function is tolerance-based (stated in the tests), not bit-exact.
+ * ---------------------------------------------------------------------------------------------- */
+static double trace2(const double *M) { return M[0] + M[3]; }
+
+/* [fs, Cs] = the trace terms of StateHessianTerms (:158-199) for one matrix pair list {F1, F2} */
+static void hessian_terms2(const double *Pk, const double *F1, const double *F2, double *f, double *Cm)
+{
+    const double *F[2] = {F1, F2};
+    double T1[4], T2[4], T3[4];
+    for (int ii = 0; ii < 2; ii++) {
+        mat_mul(2, Pk, F[ii], T1);
+        f[ii] = trace2(T1) / 2;                         /* :183 */
+        for (int jj = 0; jj < 2; jj++) {
+            mat_mul(2, T1, Pk, T2);                     /* Pk*Fs{ii}*Pk*Fs{jj}, left to right */
+            mat_mul(2, T2, F[jj], T3);
+            Cm[IX(ii, jj, 2)] = trace2(T3) / 2;         /* :185 */
+        }
+    }
+}
+
+int orc_rt_expfit_ekf(int T, const double *x, const double *s_init, const double *params, const double *w_bar,
+                      double v_bar, const double *Ps_init, const double *Q_w, double R_v, double beta, double gamma,
+                      int L, int order, double *S_MINUS, double *S_PLUS, double *P_MINUS, double *P_PLUS,
+                      double *K_GAIN, double *S_SMOOTH, double *P_SMOOTH, double *innovations, double *rho)
+{
+    if (order != 1 && order != 2) return ORC_ERR_UNDEFINED_ORDER;   /* :46,77 */
+    if (T < 1 || L < 1) return ORC_ERR_BAD_ARG;
+    const double ts = params[0], alpha = params[1], sigma = params[2];
+    double *winMean = (double *)calloc((size_t)L, sizeof(double));
+    double *winCov = (double *)calloc((size_t)L, sizeof(double));
+    double *winCovN = (double *)calloc((size_t)L, sizeof(double));
+    double sm[2] = {s_init[0], s_init[1]}, Pm[4], R = R_v;      /* :29-32 */
+    memcpy(Pm, Ps_init, sizeof Pm);
+    const double Cj[2] = {1.0, 0.0}, Dj = 1.0;                  /* ObsJacobian :151-154 */
+    for (int k = 0; k < T; k++) {
+        memcpy(S_MINUS + 2 * (size_t)k, sm, sizeof sm);         /* :37-38 */
+        memcpy(P_MINUS + 4 * (size_t)k, Pm, sizeof Pm);
+        /* ObsHessianTerms :202-227: Gs = Gv = {0} => every trace is 0 for either order */
+        const double gs = 0.0, Gsp = 0.0, gv = 0.0, Gvp = 0.0;
+        const double xk_minus = ((sm[0] + v_bar) + gs) + gv;    /* :52 */
+        double innov, K[2], sp[2], Pp[4];
+        const int valid = !isnan(x[k]);
+        if (valid) {                                            /* :55-59 */
+            innov = x[k] - xk_minus;
+            double PCt[2], CP[2];
+            for (int i = 0; i < 2; i++) PCt[i] = fma(Pm[IX(i, 1, 2)], Cj[1], Pm[IX(i, 0, 2)] * Cj[0]);
+            for (int j = 0; j < 2; j++) CP[j] = fma(Cj[1], Pm[IX(1, j, 2)], Cj[0] * Pm[IX(0, j, 2)]);
+            const double CPCt = fma(CP[1], Cj[1], CP[0] * Cj[0]);
+            const double den = ((CPCt + gamma * ((Dj * R) * Dj)) + Gsp) + Gvp;
+            for (int i = 0; i < 2; i++) K[i] = PCt[i] / den;
+            double IKC[4], T1[4];
+            for (int j = 0; j < 2; j++)
+                for (int i = 0; i < 2; i++) IKC[IX(i, j, 2)] = ((i == j) ? 1.0 : 0.0) - K[i] * Cj[j];
+            mat_mul(2, IKC, Pm, T1);
+            for (int e = 0; e < 4; e++) Pp[e] = T1[e] / gamma;
+            for (int i = 0; i < 2; i++) sp[i] = sm[i] + K[i] * innov;
+        } else {                                                /* :60-65 */
+            innov = 0.0; K[0] = K[1] = 0.0;
+            memcpy(Pp, Pm, sizeof Pp); memcpy(sp, sm, sizeof sp);
+        }
+        /* NlinStateUpdate :133-140, StateJacobians :148-160 */
+        const double E = exp(ts * sp[1]);
+        const double tnh = tanh((alpha * sp[1] + w_bar[1]) / sigma);
+        const double omt = 1 - tnh * tnh;
+        double fs[2] = {0, 0}, fw[2] = {0, 0}, Fsp[4] = {0, 0, 0, 0}, Fwp[4] = {0, 0, 0, 0};
+        if (order == 2) {                                       /* StateHessianTerms :163-199 */
+            double Fs1[4] = {0, 0, 0, 0}, Fs2[4] = {0, 0, 0, 0}, Fw1[4] = {0, 0, 0, 0}, Fw2[4] = {0, 0, 0, 0};
+            Fs1[IX(0, 1, 2)] = ts * E; Fs1[IX(1, 0, 2)] = Fs1[IX(0, 1, 2)];
+            Fs1[IX(1, 1, 2)] = ((ts * ts) * sp[0]) * E;
+            Fs2[IX(1, 1, 2)] = (((-2 * (alpha * alpha)) / sigma) * tnh) * omt;
+            Fw2[IX(1, 1, 2)] = ((-2 / sigma) * tnh) * omt;
+            hessian_terms2(Pp, Fs1, Fs2, fs, Fsp);
+            hessian_terms2(Q_w, Fw1, Fw2, fw, Fwp);
+        }
+        sm[0] = ((sp[0] * E + w_bar[0]) + fs[0]) + fw[0];       /* :81 */
+        sm[1] = ((sigma * tnh) + fs[1]) + fw[1];
+        {
+            double A[4], Bm[4] = {1, 0, 0, omt}, T1[4], T2[4], T3[4];
+            A[IX(0, 0, 2)] = E; A[IX(0, 1, 2)] = (ts * sp[0]) * E; A[IX(1, 0, 2)] = 0; A[IX(1, 1, 2)] = alpha * omt;
+            mat_mul(2, A, Pp, T1); mat_mul_bt(2, T1, A, T2);
+            mat_mul(2, Bm, Q_w, T1); mat_mul_bt(2, T1, Bm, T3);
+            for (int e = 0; e < 4; e++) Pm[e] = ((T2[e] + T3[e]) + Fsp[e]) + Fwp[e];   /* :83 */
+        }
+        memcpy(S_PLUS + 2 * (size_t)k, sp, sizeof sp);          /* :86-88 */
+        memcpy(P_PLUS + 4 * (size_t)k, Pp, sizeof Pp);
+        if (K_GAIN) { K_GAIN[2 * (size_t)k] = K[0]; K_GAIN[2 * (size_t)k + 1] = K[1]; }
+        if (innovations) innovations[k] = innov;
+        /* :91-101 */
+        const int cnt = (k + 1 < L) ? (k + 1) : L;
+        memmove(winMean + 1, winMean, sizeof(double) * (size_t)(L - 1)); winMean[0] = innov;
+        double sum = winMean[0];
+        for (int j = 1; j < L; j++) sum = sum + winMean[j];
+        const double mu = sum / cnt;
+        const double cc = (innov - mu) * (innov - mu);
+        memmove(winCov + 1, winCov, sizeof(double) * (size_t)(L - 1)); winCov[0] = cc;
+        memmove(winCovN + 1, winCovN, sizeof(double) * (size_t)(L - 1)); winCovN[0] = cc / R;
+        double sumN = winCovN[0];
+        for (int j = 1; j < L; j++) sumN = sumN + winCovN[j];
+        if (rho) rho[k] = sumN / cnt;
+        if (beta != 1.0 && valid) {
+            double sumC = winCov[0];
+            for (int j = 1; j < L; j++) sumC = sumC + winCov[j];
+            R = beta * R + (1 - beta) * sumC / cnt;
+        }
+    }
+    free(winMean); free(winCov); free(winCovN);
+    if (S_SMOOTH && P_SMOOTH) {                                  /* :105-116 */
+        double Ss[2], Ps[4];
+        memcpy(Ss, S_PLUS + 2 * (size_t)(T - 1), sizeof Ss); memcpy(Ps, P_PLUS + 4 * (size_t)(T - 1), sizeof Ps);
+        memcpy(S_SMOOTH + 2 * (size_t)(T - 1), Ss, sizeof Ss); memcpy(P_SMOOTH + 4 * (size_t)(T - 1), Ps, sizeof Ps);
+        for (int k = T - 2; k >= 0; k--) {
+            const double *sp = S_PLUS + 2 * (size_t)k, *Pp = P_PLUS + 4 * (size_t)k;
+            const double *Sm1 = S_MINUS + 2 * (size_t)(k + 1), *Pm1 = P_MINUS + 4 * (size_t)(k + 1);
+            const double E = exp(ts * sp[1]);
+            const double tnh = tanh((alpha * sp[1] + w_bar[1]) / sigma);
+            double A[4], T1[4], J[4], D[4], T2[4];
+            A[IX(0, 0, 2)] = E; A[IX(0, 1, 2)] = (ts * sp[0]) * E; A[IX(1, 0, 2)] = 0; A[IX(1, 1, 2)] = alpha * (1 - tnh * tnh);
+            mat_mul_bt(2, Pp, A, T1);
+            orc_mrdivide(2, T1, Pm1, J);                         /* :112 */
+            double dv[2] = {Ss[0] - Sm1[0], Ss[1] - Sm1[1]};
+            for (int i = 0; i < 2; i++) Ss[i] = sp[i] + fma(J[IX(i, 1, 2)], dv[1], J[IX(i, 0, 2)] * dv[0]);
+            for (int e = 0; e < 4; e++) D[e] = Pm1[e] - Ps[e];
+            mat_mul(2, J, D, T1); mat_mul_bt(2, T1, J, T2);
+            for (int e = 0; e < 4; e++) Ps[e] = Pp[e] - T2[e];
+            memcpy(S_SMOOTH + 2 * (size_t)k, Ss, sizeof Ss); memcpy(P_SMOOTH + 4 * (size_t)k, Ps, sizeof Ps);
+        }
+    }
+    return ORC_OK;
+}
+
+/* batched SoA driver with the HIP library's layout: x [T][Sx], rp [EPI_RT_PRM_COUNT][B], outputs [T][rows][B] */
+int orc_rt_expfit_batch(int B, int T, int Sx, const int *x_series, const double *x, const double *rp, int L, int order,
+                        double *S_MINUS, double *S_PLUS, double *P_MINUS, double *P_PLUS, double *K_GAIN,
+                        double *S_SMOOTH, double *P_SMOOTH, double *innovations, double *rho, int n_threads)
+{
+    int rc_all = ORC_OK;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel
+    {
+        double *xs = (double *)malloc(sizeof(double) * (size_t)T);
+        double *buf = (double *)malloc(sizeof(double) * (size_t)T * 22);
+        double *SM = buf, *SP = SM + 2 * (size_t)T, *PM = SP + 2 * (size_t)T, *PP = PM + 4 * (size_t)T, *KG = PP + 4 * (size_t)T;
+        double *SS = KG + 2 * (size_t)T, *PS = SS + 2 * (size_t)T, *inn = PS + 4 * (size_t)T, *rh = inn + T;
+#pragma omp for schedule(dynamic, 16)
+        for (int c = 0; c < B; c++) {
+            const int sx = x_series ? x_series[c] : c;
+            for (int k = 0; k < T; k++) xs[k] = x[(size_t)k * Sx + sx];
+#define RP(f) rp[(size_t)(f) * B + c]
+            const double params[3] = {RP(0), RP(1), RP(2)}, w_bar[2] = {RP(3), RP(4)}, s_init[2] = {RP(9), RP(10)};
+            const double Pi[4] = {RP(11), RP(12), RP(13), RP(14)}, Q[4] = {RP(15), RP(16), RP(17), RP(18)};
+            int rc = orc_rt_expfit_ekf(T, xs, s_init, params, w_bar, RP(5), Pi, Q, RP(6), RP(7), RP(8), L, order,
+                                       SM, SP, PM, PP, KG, SS, PS, inn, rh);
+#undef RP
+            if (rc != ORC_OK) {
+#pragma omp critical
+                rc_all = rc;
+                continue;
+            }
+            for (int k = 0; k < T; k++) {
+                for (int i = 0; i < 2; i++) {
+                    if (S_MINUS) S_MINUS[((size_t)k * 2 + i) * B + c] = SM[i + 2 * (size_t)k];
+                    if (S_PLUS) S_PLUS[((size_t)k * 2 + i) * B + c] = SP[i + 2 * (size_t)k];
+                    if (K_GAIN) K_GAIN[((size_t)k * 2 + i) * B + c] = KG[i + 2 * (size_t)k];
+                    if (S_SMOOTH) S_SMOOTH[((size_t)k * 2 + i) * B + c] = SS[i + 2 * (size_t)k];
+                }
+                for (int e = 0; e < 4; e++) {
+                    if (P_MINUS) P_MINUS[((size_t)k * 4 + e) * B + c] = PM[e + 4 * (size_t)k];
+                    if (P_PLUS) P_PLUS[((size_t)k * 4 + e) * B + c] = PP[e + 4 * (size_t)k];
+                    if (P_SMOOTH) P_SMOOTH[((size_t)k * 4 + e) * B + c] = PS[e + 4 * (size_t)k];
+                }
+                if (innovations) innovations[(size_t)k * B + c] = inn[k];
+                if (rho) rho[(size_t)k * B + c] = rh[k];
+            }
+        }
+        free(xs); free(buf);
+    }
+    return rc_all;
+}

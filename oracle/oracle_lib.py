@@ -256,3 +256,42 @@ def pareto_front(J0, J1):
     on = np.zeros(a.shape[0], dtype=np.int32); io = C.c_int(0)
     lib().orc_pareto_front(C.c_int(a.shape[0]), _dp(a), _dp(b), on.ctypes.data_as(C.POINTER(C.c_int)), C.byref(io))
     return on.astype(bool), io.value
+
+
+RT_PRM_COUNT = 19      # rows of the Rt_ExpFitEKF parameter block, include/epiekf.h EPI_RT_*
+RT_OUT_ROWS = {"S_MINUS": 2, "S_PLUS": 2, "P_MINUS": 4, "P_PLUS": 4, "K_GAIN": 2, "S_SMOOTH": 2, "P_SMOOTH": 4,
+               "innovations": 0, "rho": 0}
+
+
+def rt_expfit(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma, inv_monitor_len, order):
+    """Tools/Rt_ExpFitEKF.m through the C oracle; returns dict name -> MATLAB-shaped array."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1)); T = x.shape[0]
+    f = lambda a: np.asfortranarray(np.asarray(a, dtype=np.float64))
+    si, pr, wb, Pi, Q = f(np.reshape(s_init, -1)), f(np.reshape(params, -1)), f(np.reshape(w_bar, -1)), f(Ps_init), f(Q_w)
+    out = {"S_MINUS": np.zeros((2, T), order="F"), "S_PLUS": np.zeros((2, T), order="F"),
+           "P_MINUS": np.zeros((2, 2, T), order="F"), "P_PLUS": np.zeros((2, 2, T), order="F"),
+           "K_GAIN": np.zeros((2, 1, T), order="F"), "S_SMOOTH": np.zeros((2, T), order="F"),
+           "P_SMOOTH": np.zeros((2, 2, T), order="F"), "innovations": np.zeros((1, T)), "rho": np.zeros(T)}
+    rc = lib().orc_rt_expfit_ekf(C.c_int(T), _dp(x), _dp(si), _dp(pr), _dp(wb), C.c_double(float(v_bar)), _dp(Pi), _dp(Q),
+                                 C.c_double(float(R_v)), C.c_double(float(beta)), C.c_double(float(gamma)),
+                                 C.c_int(int(inv_monitor_len)), C.c_int(int(order)),
+                                 *[_dp(out[n]) for n in ("S_MINUS", "S_PLUS", "P_MINUS", "P_PLUS", "K_GAIN", "S_SMOOTH",
+                                                         "P_SMOOTH", "innovations", "rho")])
+    if rc != 0:
+        raise OracleError(ERRORS.get(rc, str(rc)))
+    return out
+
+
+def rt_expfit_batch(x, rp, L, order, x_series=None, n_threads=0):
+    """Batched Rt_ExpFitEKF, HIP-library layout: x [T, Sx], rp [19, B]; returns dict name -> [T, rows, B] / [T, B]."""
+    x = _f(x); rp = _f(rp)
+    T, Sx = x.shape; B = rp.shape[1]
+    xs = None if x_series is None else np.ascontiguousarray(x_series, dtype=np.int32)
+    out = {n: np.zeros((T, B) if r == 0 else (T, r, B)) for n, r in RT_OUT_ROWS.items()}
+    rc = lib().orc_rt_expfit_batch(C.c_int(B), C.c_int(T), C.c_int(Sx), None if xs is None else xs.ctypes.data_as(C.POINTER(C.c_int)),
+                                   _dp(x), _dp(rp), C.c_int(int(L)), C.c_int(int(order)),
+                                   *[_dp(out[n]) for n in ("S_MINUS", "S_PLUS", "P_MINUS", "P_PLUS", "K_GAIN", "S_SMOOTH",
+                                                           "P_SMOOTH", "innovations", "rho")], C.c_int(int(n_threads)))
+    if rc != 0:
+        raise OracleError(ERRORS.get(rc, str(rc)))
+    return out

@@ -77,5 +77,32 @@ int main(void)
         orc_seirp_saturated(par[0], par[1], par[2], par[3], par[6], 0.99, 0.01, 0, 0, 0, 60, 0.1, 0.1, 0.02, 0.02, 0.08, 0.01, 0.05, out[0], out[1], out[2], out[3], out[4]);
         printf("sims ok J0=%.3e J1=%.3e\n", J0, J1);
     }
+    /* scenario generation / selection and Rt_ExpFitEKF */
+    {
+        const int K = 30, P = 40;
+        double lo[12], hi[12], plan[12 * 30], J0[40], J1[40];
+        int on[40], io;
+        for (int k = 0; k < 12; k++) { lo[k] = 0; hi[k] = 2 + (k % 3); }
+        orc_random_npi_plan(7u, 9u, 3, 0, 10, 12, K, lo, hi, plan);
+        orc_random_npi_plan(7u, 9u, 3, 9, 10, 12, K, lo, hi, plan);
+        for (int q = 0; q < P; q++) { J0[q] = lcg(&seed); J1[q] = lcg(&seed); }
+        J0[5] = NAN;
+        orc_pareto_front(P, J0, J1, on, &io);
+        orc_pareto_front(1, J0, J1, on, &io);
+        const int Tr = 45, Br = 3;
+        double xr[45 * 2], rp[19 * 3], o2[3][45 * 2 * 3], o4[3][45 * 4 * 3], kg[45 * 2 * 3], inn[45 * 3], rho[45 * 3];
+        int xsr[3] = {0, 1, 0};
+        for (int t = 0; t < Tr * 2; t++) xr[t] = (t % 13 == 5) ? NAN : 500 + 100 * lcg(&seed);
+        for (int c = 0; c < Br; c++) {
+            const double col[19] = {1, 0.9, 0.1, 0.1, 1e-4, 0, 100, 0.9, 0.995, 500, 0.01, 6.25e6, 0, 0, 9e-4, 62500, 0, 0, 9e-6};
+            for (int f = 0; f < 19; f++) rp[f * Br + c] = col[f];
+        }
+        for (int order = 1; order <= 2; order++) {
+            int rc = orc_rt_expfit_batch(Br, Tr, 2, xsr, xr, rp, 21, order, o2[0], o2[1], o4[0], o4[1], kg, o2[2], o4[2], inn, rho, 1);
+            if (rc != 0) { printf("rt_expfit order %d failed rc=%d\n", order, rc); return 1; }
+        }
+        if (orc_rt_expfit_batch(Br, Tr, 2, xsr, xr, rp, 21, 3, o2[0], o2[1], o4[0], o4[1], kg, o2[2], o4[2], inn, rho, 1) != ORC_ERR_UNDEFINED_ORDER) return 1;
+        printf("scenarios + rt_expfit ok, i_opt=%d S_SMOOTH[0]=%.6e\n", io, o2[2][0]);
+    }
     return 0;
 }

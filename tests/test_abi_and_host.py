@@ -187,3 +187,27 @@ def test_shard_chains_partitions_exactly():
             spans = [shard_chains(B, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == B
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def test_rt_expfit_validate_and_tools_errors(hip_lib):
+    from epidemicmodeling_amd import _lib, tools
+    from epidemicmodeling_amd.tools import EpiError
+
+    def d(**kw):
+        r = _lib.RtDesc()
+        base = dict(abi_version=1, B=4, T=10, Sx=4, L=21, order=1); base.update(kw)
+        for k, v in base.items():
+            setattr(r, k, v)
+        return r
+    err = C.create_string_buffer(256)
+    assert hip_lib.epi_rt_expfit_validate(C.byref(d()), err) == 0
+    assert hip_lib.epi_rt_expfit_validate(C.byref(d(order=2)), err) == 0
+    assert hip_lib.epi_rt_expfit_validate(C.byref(d(order=3)), err) == -1 and err.value == b"Undefined order"
+    assert hip_lib.epi_rt_expfit_validate(C.byref(d(T=0)), err) == -5
+    assert hip_lib.epi_rt_expfit_validate(C.byref(d(L=107)), err) == -8
+    outs = _lib.RtOutputs()
+    assert hip_lib.epi_rt_expfit_run_device(C.byref(d()), None, None, None, C.byref(outs), None, err) == -5
+    with pytest.raises(EpiError, match="Undefined order"):       # Rt_ExpFitEKF.m:46
+        tools.Rt_ExpFitEKF(np.ones((1, 5)), [1.0, 0.0], [1, 0.9, 0.1], [0, 0], 0, np.eye(2), np.eye(2), 1.0, 0.9, 0.995, 21, 0)
+    with pytest.raises(IndexError):                              # params(3) on a 2-vector
+        tools.Rt_ExpFitEKF(np.ones((1, 5)), [1.0, 0.0], [1, 0.9], [0, 0], 0, np.eye(2), np.eye(2), 1.0, 0.9, 0.995, 21, 1)
