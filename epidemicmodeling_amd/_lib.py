@@ -10,7 +10,8 @@ import os
 from . import layout as L
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libepiekf.so")
+# EPIEKF_LIB: load another build of the same ABI instead (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",

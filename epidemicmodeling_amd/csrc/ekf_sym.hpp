@@ -91,6 +91,49 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
 #ifndef EPI_BWD_LB
 #define EPI_BWD_LB kWave
 #endif
+// P(k+1|k) = sym(A P(k|k) A' + Q), Q diagonal (GenericEKF.m:158-161), packed in and out.  One ROW at a time with
+// the structural zeros of A skipped: row i of T1 = A P is formed, consumed into row i of the full result G, and as
+// soon as both G(i,j) and G(j,i) exist they are averaged into the packed result.  Shared by ekf_fwd_sym and by
+// eks_bwd_sym, which recomputes P(k+1|k) from the stored P(k|k) instead of reading it back: same function, same
+// operands, same bits.
+template <int M>
+EPI_DEV void predict_cov_sym(const double (&A)[M * M], const double (&Pp)[M * (M + 1) / 2], const double (&Qd)[M],
+                             double (&Pm)[M * (M + 1) / 2])
+{
+    double G[M * M];
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        double T1r[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double acc = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int q = 0; q < M; q++)
+                if (a_nz<M>(i, q)) {
+                    acc = first ? A[IXM(i, q)] * Pp[sidx(q, j)] : fma(A[IXM(i, q)], Pp[sidx(q, j)], acc);
+                    first = false;
+                }
+            T1r[j] = acc;
+        }
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double acc = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int q = 0; q < M; q++)
+                if (a_nz<M>(j, q)) {
+                    acc = first ? T1r[q] * A[IXM(j, q)] : fma(T1r[q], A[IXM(j, q)], acc);
+                    first = false;
+                }
+            G[IXM(i, j)] = acc + ((i == j) ? Qd[i] : 0.0);
+        }
+#pragma unroll
+        for (int j = 0; j < i; j++) Pm[sidx(j, i)] = (G[IXM(i, j)] + G[IXM(j, i)]) / 2.0;
+        Pm[sidx(i, i)] = (G[IXM(i, i)] + G[IXM(i, i)]) / 2.0;
+    }
+}
+
 template <int M, int FLIP>
 __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
@@ -228,40 +271,9 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
         store_u(a.u_opt, a, t, c, u_app);
         {
-            double A[M * M], G[M * M];
+            double A[M * M];
             state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
-            // P- = sym(A P+ A' + Q), Q diagonal; row by row as above, structural zeros of A skipped
-#pragma unroll
-            for (int i = 0; i < M; i++) {
-                double T1r[M];
-#pragma unroll
-                for (int j = 0; j < M; j++) {
-                    double acc = 0.0;
-                    bool first = true;
-#pragma unroll
-                    for (int q = 0; q < M; q++)
-                        if (a_nz<M>(i, q)) {
-                            acc = first ? A[IXM(i, q)] * Pp[sidx(q, j)] : fma(A[IXM(i, q)], Pp[sidx(q, j)], acc);
-                            first = false;
-                        }
-                    T1r[j] = acc;
-                }
-#pragma unroll
-                for (int j = 0; j < M; j++) {
-                    double acc = 0.0;
-                    bool first = true;
-#pragma unroll
-                    for (int q = 0; q < M; q++)
-                        if (a_nz<M>(j, q)) {
-                            acc = first ? T1r[q] * A[IXM(j, q)] : fma(T1r[q], A[IXM(j, q)], acc);
-                            first = false;
-                        }
-                    G[IXM(i, j)] = acc + ((i == j) ? Qd[i] : 0.0);
-                }
-#pragma unroll
-                for (int j = 0; j < i; j++) Pm[sidx(j, i)] = (G[IXM(i, j)] + G[IXM(j, i)]) / 2.0;
-                Pm[sidx(i, i)] = (G[IXM(i, i)] + G[IXM(i, i)]) / 2.0;
-            }
+            predict_cov_sym<M>(A, Pp, Qd, Pm);
         }
         state_hard_margins<M>(p, sk_minus);
 
@@ -297,8 +309,8 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
 // backward recursion, symmetric-packed (X = pinv(P_MINUS) comes from eks_pinv)
 // ---------------------------------------------------------------------------
 template <int M>
-struct BwdIn {   // everything smoother step k reads: forward quantities of steps k and k+1
-    double Sp[M], Pp[M * (M + 1) / 2], u[kNpi], X[M * M], Sm1[M], Pm1[M * (M + 1) / 2];
+struct BwdIn {   // everything smoother step k reads: forward quantities of step k and X = pinv(P(k+1|k))
+    double Sp[M], Pp[M * (M + 1) / 2], u[kNpi], X[M * M];
     int rk;
 };
 template <int M, int FLIP>
@@ -322,6 +334,10 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         vlds[(2 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
         vlds[(3 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
     }
+
+    double Qd[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) Qd[i] = a.Q[(size_t)IXM(i, i) * B + c];
 
     // terminal conditions GenericEKF.m:189-202.  Ps_final overrides entry by entry; ekf_precheck guarantees it
     // is symmetric (values and NaN pattern), so P_SMOOTH(:,:,T) is symmetric and stays packed.
@@ -364,8 +380,6 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         load_u(a, t, su, d.u);
         d.rk = ldg_i(a.rankbuf + (size_t)t1 * B, (unsigned)c * 4u);
         load_packed<M>(a.X, t1, B, c, d.X);       // unused garbage where the :211 guard fired (rk < 0)
-        load_vec<M>(a.S_MINUS, t1, B, c, d.Sm1);
-        load_sym<M>(a.P_MINUS, t1, B, c, d.Pm1);
     };
     int t_pend = -1, rank_pend = -1;
     double u_pend[kNpi];
@@ -383,6 +397,19 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         const int t = tpos<FLIP>(k, T);
         fetch(k, cur);
         flush();
+        // s(k+1|k) and P(k+1|k) are NOT read back: they are recomputed from the stored s(k|k), P(k|k), u(:,k) with
+        // the forward kernel's own functions (:155-164) -- bit-identical, and 27 fewer loads per step for a kernel
+        // that is bound by the number of memory operations a CU can issue
+        double A[M * M], Sm1[M], Pm1[NS];
+        state_jacobians<M, FLIP>(p, cur.u, cur.Sp, A);         // :206 (and :157 of the forward pass)
+        {
+            double u_app[kNpi];
+#pragma unroll
+            for (int q = 0; q < kNpi; q++) u_app[q] = cur.u[q];
+            nlin_state_update<M, FLIP>(p, a.mf, u_app, cur.Sp, Sm1);
+            state_hard_margins<M>(p, Sm1);
+        }
+        predict_cov_sym<M>(A, cur.Pp, Qd, Pm1);
         double J[M * M];
         int rank = -1;
         if (cur.rk < 0) {                                      // non-finite P_MINUS guard :211-213
@@ -390,8 +417,6 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             for (int e = 0; e < M * M; e++) J[e] = 0.0;
             st_guard = 1;
         } else {
-            double A[M * M];
-            state_jacobians<M, FLIP>(p, cur.u, cur.Sp, A);     // :206
             // J = (P+ A') X  :215, one row at a time (zeros of A skipped): row i of P+ A' is consumed into
             // row i of J at once, so the 6 x 6 product P+ A' is never live as a whole
 #pragma unroll
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         {
             double dv[M];
 #pragma unroll
-            for (int i = 0; i < M; i++) dv[i] = Ss[i] - cur.Sm1[i];
+            for (int i = 0; i < M; i++) dv[i] = Ss[i] - Sm1[i];
 #pragma unroll
             for (int i = 0; i < M; i++) {
                 double acc = J[IXM(i, 0)] * dv[0];
@@ -441,7 +466,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             // (see ekf_fwd_sym)
             double Dsym[NS];
 #pragma unroll
-            for (int e = 0; e < NS; e++) Dsym[e] = cur.Pm1[e] - Ps[e];
+            for (int e = 0; e < NS; e++) Dsym[e] = Pm1[e] - Ps[e];
             double F[M * M];
 #pragma unroll
             for (int i = 0; i < M; i++) {
