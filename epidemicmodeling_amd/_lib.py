@@ -18,6 +18,7 @@ ABI_SYMBOLS = [
     "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_calib_copy_f64_device",
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
+    "epi_preprocess_workspace_bytes", "epi_preprocess_device",
 ]
 
 
@@ -65,6 +66,17 @@ RT_OUT_NAMES = ("S_MINUS", "S_PLUS", "P_MINUS", "P_PLUS", "K_GAIN", "S_SMOOTH", 
 
 class RtOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in RT_OUT_NAMES]
+
+
+class PreDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "S", "T", "n_npi", "W", "first_num_days")] + [("min_cases", C.c_double)]
+
+
+PRE_OUT_NAMES = ("new_refined", "new_smoothed", "zero_lag", "x_new", "x_total", "R_v", "fatality", "I0", "ip_filled")
+
+
+class PreOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in PRE_OUT_NAMES]
 
 
 _lib = None
@@ -132,6 +144,11 @@ def lib():
         h.epi_rt_expfit_run_host.restype = C.c_int
         h.epi_rt_expfit_run_host.argtypes = [C.POINTER(RtDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(RtOutputs),
                                              C.c_int, C.c_char_p]
+        h.epi_preprocess_workspace_bytes.restype = C.c_size_t
+        h.epi_preprocess_workspace_bytes.argtypes = [C.POINTER(PreDesc)]
+        h.epi_preprocess_device.restype = C.c_int
+        h.epi_preprocess_device.argtypes = [C.POINTER(PreDesc)] + [C.c_void_p] * 4 + [C.POINTER(PreOutputs), C.c_void_p,
+                                                                                        C.c_size_t, C.c_void_p, C.c_char_p]
         h.epi_calib_copy_f64_device.restype = C.c_int
         h.epi_calib_copy_f64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p]
         if h.epi_abi_version() != 1:

@@ -236,6 +236,44 @@ def pareto_front(J0, J1, n_regions):
     return on.bool(), io
 
 
+def preprocess(cases, population, deaths=None, ip=None, W=7, min_cases=1.0, first_num_days=7, outputs=None,
+               device="cuda:0"):
+    """Per-region preprocessing on the device (Tools/TrainPredictPrescribeNPI.m:142-198,201-202,240).
+
+    cases / deaths: cumulative confirmed counts [T, S] (NaN = missing), population [S], ip [T, n_npi, S] (NaN = N/A).
+    Returns dict of torch tensors in the filters' input layout: x_new / x_total / R_v / new_refined / new_smoothed /
+    zero_lag / fatality [T, S], I0 [S], ip_filled [T, n_npi, S] (those in `outputs`; default: all that apply)."""
+    dev = torch.device(device)
+    t = lambda a: None if a is None else (a if isinstance(a, torch.Tensor) else
+                                          torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev))
+    cases, population, deaths, ip = t(cases), t(population), t(deaths), t(ip)
+    T, S = cases.shape
+    names = list(_lib.PRE_OUT_NAMES) if outputs is None else list(outputs)
+    if deaths is None and "fatality" in names:
+        names.remove("fatality")
+    if ip is None and "ip_filled" in names:
+        names.remove("ip_filled")
+    d = _lib.PreDesc()
+    d.abi_version, d.S, d.T, d.n_npi = 1, S, T, 0 if ip is None else ip.shape[1]
+    d.W, d.first_num_days, d.min_cases = int(W), int(first_num_days), float(min_cases)
+    out = {}
+    for n in names:
+        shape = (S,) if n == "I0" else (tuple(ip.shape) if n == "ip_filled" else (T, S))
+        out[n] = torch.empty(shape, dtype=torch.float64, device=dev)
+    outs = _lib.PreOutputs()
+    for n in _lib.PRE_OUT_NAMES:
+        setattr(outs, n, _ptr(out.get(n)))
+    h = _lib.lib()
+    wsb = int(h.epi_preprocess_workspace_bytes(C.byref(d)))
+    ws = torch.empty(max(wsb // 8, 1), dtype=torch.float64, device=dev)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = h.epi_preprocess_device(C.byref(d), _ptr(cases), _ptr(deaths), _ptr(population), _ptr(ip), C.byref(outs),
+                                 _ptr(ws), wsb, C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return out
+
+
 RT_OUT_ROWS = {"S_MINUS": 2, "S_PLUS": 2, "P_MINUS": 4, "P_PLUS": 4, "K_GAIN": 2, "S_SMOOTH": 2, "P_SMOOTH": 4,
                "innovations": 0, "rho": 0}
 

@@ -590,6 +590,7 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
 
 #include "scenario_kernels.hpp"
 #include "rt_expfit.hpp"
+#include "preprocess.hpp"
 
 struct SeirpRates { double ae, ai, kappa, rho, beta, mu, gamma; };
 EPI_DEV void seirp_rhs(const SeirpRates &r, const double (&y)[5], double (&f)[5])
@@ -1250,6 +1251,63 @@ int epi_rt_expfit_run_host(const epi_rt_desc *d, const int32_t *x_series, const 
     for (auto &o : outs)
         if (o.host && (e = hipMemcpy(o.host, *o.dev, o.bytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
     for (void *p : allocs) (void)hipFree(p);
+    return EPI_OK;
+}
+
+static int pre_validate(const epi_pre_desc *d, int *W2, int *nfact, char *err)
+{
+    if (!d || d->abi_version != EPIEKF_ABI_VERSION || d->S < 1 || d->n_npi < 0 || d->n_npi > EPI_MAX_NPI || d->first_num_days < 0) {
+        set_err(err, "bad preprocessing descriptor"); return EPI_ERR_BAD_ARG;
+    }
+    if (d->W < 1 || d->W > kPreMaxTaps) { set_err(err, "SmoothingWinLen out of range 1..32"); return EPI_ERR_BAD_ARG; }
+    if (d->T < 2) { set_err(err, "Insufficient data"); return EPI_ERR_BAD_ARG; }            // :168
+    int w2 = (int)floor((double)d->W / 2 + 0.5);                                            // MATLAB round()
+    if (w2 < 1) w2 = 1;
+    const int nf = (3 * (w2 - 1) > 1) ? 3 * (w2 - 1) : 1;
+    if (d->T <= nf) {
+        char b[96]; snprintf(b, sizeof b, "Data length must be larger than %d samples.", nf);
+        set_err(err, b); return EPI_ERR_BAD_ARG;
+    }
+    *W2 = w2; *nfact = nf;
+    return EPI_OK;
+}
+
+size_t epi_preprocess_workspace_bytes(const epi_pre_desc *d)
+{
+    int W2, nfact;
+    if (pre_validate(d, &W2, &nfact, nullptr) != EPI_OK) return 0;
+    return ((size_t)3 * d->T + 2 * (size_t)nfact) * (size_t)d->S * sizeof(double);
+}
+
+int epi_preprocess_device(const epi_pre_desc *d, const double *cases, const double *deaths, const double *population,
+                          const double *ip, const epi_pre_outputs *out, void *workspace, size_t workspace_bytes,
+                          void *stream, char *err)
+{
+    int W2 = 0, nfact = 0;
+    int rc = pre_validate(d, &W2, &nfact, err);
+    if (rc != EPI_OK) return rc;
+    if (!cases || !population || !out) { set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG; }
+    if (out->ip_filled && (!ip || d->n_npi < 1)) { set_err(err, "ip_filled selected without ip"); return EPI_ERR_BAD_ARG; }
+    if (out->fatality && !deaths) { set_err(err, "fatality selected without deaths"); return EPI_ERR_BAD_ARG; }
+    if (!workspace || workspace_bytes < epi_preprocess_workspace_bytes(d)) {
+        set_err(err, epi_status_string(EPI_ERR_WORKSPACE)); return EPI_ERR_WORKSPACE;
+    }
+    PreArgs a{};
+    a.T = d->T; a.S = d->S; a.W = d->W; a.W2 = W2; a.nfact = nfact; a.first_num_days = d->first_num_days;
+    a.min_cases = d->min_cases;
+    a.cases = cases; a.deaths = deaths; a.population = population;
+    a.new_refined = out->new_refined; a.new_smoothed = out->new_smoothed; a.zero_lag = out->zero_lag;
+    a.x_new = out->x_new; a.x_total = out->x_total; a.R_v = out->R_v; a.fatality = out->fatality; a.I0 = out->I0;
+    a.ws = (double *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(preprocess_regions, dim3((d->S + 63) / 64), dim3(64), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "preprocess_regions launch");
+    if (out->ip_filled) {
+        const int cols = d->n_npi * d->S;
+        hipLaunchKernelGGL(npi_fill, dim3((cols + 255) / 256), dim3(256), 0, st, d->T, cols, ip, out->ip_filled);
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "npi_fill launch");
+    }
     return EPI_OK;
 }
 

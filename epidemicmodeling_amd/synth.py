@@ -523,3 +523,28 @@ def make_rt(n_regions=40, T=300, n_draws=1, order=1, horizon=0, seed=0, w_bar=(0
     rp[11], rp[14] = 100 * q1, 100 * q2
     return RtWorkload(x=np.ascontiguousarray(x), rp=rp, x_series=rr.astype(np.int32) if n_draws > 1 else None, L=L,
                       order=order)
+
+
+def make_raw_counts(n_regions=60, T=420, seed=0, missing=0.01, n_npi=12):
+    """Synthetic data-set columns of the shape the reference ingests (OxCGRT_latest.csv: cumulative ConfirmedCases /
+    ConfirmedDeaths and the 12 NPI levels per region and day), with the defects the cleaning code handles: missing
+    days, downward corrections of the cumulative count, a missing last day, N/A NPI levels (leading and interior)."""
+    rng = np.random.default_rng(seed)
+    N = 10.0 ** rng.uniform(5, 9, n_regions)
+    growth = np.cumsum(rng.normal(0.0, 0.03, (T, n_regions)), axis=0)
+    lam = np.clip(20.0 * np.exp(np.clip(growth, -3, 7)), 0, N[None] * 1e-3)
+    daily = rng.poisson(lam).astype(np.float64)
+    cases = np.cumsum(daily, axis=0)
+    deaths = np.cumsum(rng.poisson(0.02 * lam).astype(np.float64), axis=0)
+    for arr in (cases, deaths):
+        arr[rng.random(arr.shape) < missing] = np.nan
+        for r in range(0, n_regions, 5):                      # data revisions: the cumulative count drops
+            t0 = int(rng.integers(min(30, T // 3), max(T - 30, T // 3 + 1)))
+            arr[t0:, r] -= np.floor(0.3 * daily[t0, r] + 5)
+    cases[-1, ::3] = np.nan; cases[-2, ::6] = np.nan; deaths[-1, 1::4] = np.nan
+    cases[:, -1] = np.nan                                      # a region with no data at all
+    ip = np.floor(rng.random((T, n_npi, n_regions)) * (IP_MAXES[None, :n_npi, None] + 1))
+    ip = np.maximum.accumulate(ip * (rng.random(ip.shape) < 0.05), axis=0)     # step-like policies
+    ip[rng.random(ip.shape) < 0.03] = np.nan
+    ip[:4, ::2, ::2] = np.nan
+    return {"cases": cases, "deaths": deaths, "population": N, "ip": ip}

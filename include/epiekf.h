@@ -264,6 +264,37 @@ int epi_rt_expfit_run_device(const epi_rt_desc *d, const int32_t *x_series, cons
 int epi_rt_expfit_run_host(const epi_rt_desc *d, const int32_t *x_series, const double *x, const double *rp,
                            const epi_rt_outputs *out, int device, char *err);
 
+/* ---- per-region preprocessing: data-set columns -> filter inputs (Tools/TrainPredictPrescribeNPI.m:142-198,201-202,240) ----
+ * All series are [T][S] (day-major, region-minor) -- the x / R_series layout of epi_inputs; ip / ip_filled are
+ * [T][n_npi][S] -- the u layout.  cases (and deaths, optional) are CUMULATIVE confirmed counts with NaN for missing
+ * days; population [S].  For every region:
+ *   new_refined  = diff([c(1); c]), negatives -> 0, a NaN last day <- last valid day, other NaN -> 0      (:166-178)
+ *   new_smoothed = filter(ones(1,W), W, new_refined)                                                        (:173)
+ *   zero_lag     = filtfilt(ones(1,W2), W2, new_refined), W2 = round(W/2)                                   (:174)
+ *   x_new = new_smoothed / N;  x_total = cumsum(new_smoothed) / N                                           (:175-180)
+ *   R_v   = 0.1 * ((zero_lag - new_refined) / N).^2                                                         (:240)
+ *   fatality = cumsum(filter(.., deaths part)) ./ cumsum(new_smoothed), NaN -> 0                            (:183-197)
+ *   I0    = max(min_cases, mean(first `first_num_days` positive samples of new_smoothed))                   (:201-202)
+ *   ip_filled: N/A (NaN) levels take the previous day's level, leading N/A -> 0                            (:142-150)
+ * Any output pointer may be NULL.  T must exceed 3*(W2-1) (filtfilt's 'Data length must be larger than ...'
+ * error) and be >= 2 (:168 'Insufficient data'); 1 <= W <= 32. */
+typedef struct epi_pre_desc {
+    int32_t abi_version;
+    int32_t S, T, n_npi;
+    int32_t W;               /* SmoothingWinLen (7 in the reference) */
+    int32_t first_num_days;  /* first_num_days_for_case_estimation */
+    double min_cases;
+} epi_pre_desc;
+typedef struct epi_pre_outputs {
+    double *new_refined, *new_smoothed, *zero_lag, *x_new, *x_total, *R_v, *fatality;   /* [T][S] */
+    double *I0;                                                                         /* [S] */
+    double *ip_filled;                                                                  /* [T][n_npi][S] */
+} epi_pre_outputs;
+size_t epi_preprocess_workspace_bytes(const epi_pre_desc *d);
+int epi_preprocess_device(const epi_pre_desc *d, const double *cases, const double *deaths, const double *population,
+                          const double *ip, const epi_pre_outputs *out, void *workspace, size_t workspace_bytes,
+                          void *stream, char *err);
+
 /* SEIRP.m:1-32 / SEIRPSaturatedResource.m:1-38 batched: par [K][7][B] per-step parameter arrays in the
  * order alpha_e, alpha_i, kappa, rho, beta, mu, gamma (or constant-in-time: par [1][7][B], par_steps=1);
  * init [5][B] = s0,e0,i0,r0,p0; out [K][5][B].  saturated != 0: sat [6][B] = beta_0,beta_s,mu_0,mu_s,

@@ -559,3 +559,50 @@ def rt_expfit_ekf(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamm
         S_SMOOTH[:, k] = S_PLUS[:, k] + J @ (S_SMOOTH[:, k + 1] - S_MINUS[:, k + 1])
         P_SMOOTH[:, :, k] = P_PLUS[:, :, k] - J @ (P_MINUS[:, :, k + 1] - P_SMOOTH[:, :, k + 1]) @ J.T
     return S_MINUS, S_PLUS, P_MINUS, P_PLUS, K_GAIN, S_SMOOTH, P_SMOOTH, innovations, rho
+
+
+# ---------------------------------------------------------------------------------------------------
+# Per-region preprocessing (TrainPredictPrescribeNPI.m:142-198,201-202,240) -- independent reading on
+# scipy.signal's lfilter / filtfilt, which implement the same published definitions as MATLAB's
+# ---------------------------------------------------------------------------------------------------
+def preprocess_region(cases, deaths, N_population, W=7, min_cases=1.0, first_num_days=7):
+    from scipy.signal import filtfilt, lfilter
+
+    def refine(cum):
+        cum = np.asarray(cum, dtype=np.float64)
+        d = np.diff(np.concatenate(([cum[0]], cum)))
+        d[d < 0] = 0
+        r = d.copy()
+        if np.isnan(d[-1]):
+            ok = np.flatnonzero(~np.isnan(d))
+            if ok.size:
+                r[-1] = r[ok[-1]]
+        r[np.isnan(r)] = 0
+        return r
+
+    ref = refine(cases)
+    sm = lfilter(np.ones(W), W, ref)
+    W2 = int(np.floor(W / 2 + 0.5))
+    # a single tap is the identity (SciPy's lfilter_zi rejects it; MATLAB pads one sample and returns x)
+    zl = ref.copy() if W2 <= 1 else filtfilt(np.ones(W2), W2, ref, padtype="odd", padlen=3 * (W2 - 1))
+    cs = np.cumsum(sm)
+    out = {"new_refined": ref, "new_smoothed": sm, "zero_lag": zl, "x_new": sm / N_population,
+           "x_total": cs / N_population, "R_v": 0.1 * ((zl - ref) / N_population) ** 2}
+    first = np.flatnonzero(sm > 0)[:first_num_days]
+    out["I0"] = max(min_cases, float(np.mean(sm[first]))) if first.size else float(min_cases)
+    if deaths is not None:
+        with np.errstate(all="ignore"):
+            fr = np.cumsum(lfilter(np.ones(W), W, refine(deaths))) / cs
+        fr[np.isnan(fr)] = 0
+        out["fatality"] = fr
+    return out
+
+
+def npi_fill(ip):
+    ip = np.array(ip, dtype=np.float64)
+    for j in range(ip.shape[1]):
+        for i in range(1, ip.shape[0]):
+            if np.isnan(ip[i, j]) and not np.isnan(ip[i - 1, j]):
+                ip[i, j] = ip[i - 1, j]
+    ip[np.isnan(ip)] = 0
+    return ip

@@ -1144,3 +1144,149 @@ int orc_rt_expfit_batch(int B, int T, int Sx, const int *x_series, const double 
     }
     return rc_all;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-region preprocessing feeding the filters: Tools/TrainPredictPrescribeNPI.m:152-198,240
+ * (the same block again at :97-112 for the "ENTIRE" span and in ForecastQualityAssessment.m).
+ *
+ * `filter` is a MATLAB built-in and `filtfilt` belongs to the Signal Processing Toolbox -- neither is in the
+ * reference checkout.  Restated from their published definitions:
+ *   filter(b, a, x): coefficients normalised by a(1); direct form II transposed,
+ *       y(n) = b1 x(n) + z1(n-1),  z_i(n) = b_{i+1} x(n) + z_{i+1}(n-1),  z_{nb-1}(n) = b_nb x(n).
+ *   filtfilt(b, a, x) (Gustafsson 1996, as in the toolbox and SciPy): nfact = 3 (max(nb, na) - 1) samples of odd
+ *       reflection at both ends, zi = steady-state DF-II-T state for a unit step (zi(nb-1) = b(nb),
+ *       zi(i) = b(i+1) + zi(i+1)), forward pass from zi * e(1), time reversal, second pass from zi * y(1), reversal,
+ *       padding removed.  Coefficients normalised by a(1) first, like filter does.
+ * ---------------------------------------------------------------------------------------------- */
+#define PRE_MAX_TAPS 32
+
+/* y = filter(ones(1, W), W, x) */
+static void causal_ma(int T, const double *x, int W, double *y)
+{
+    const double c = 1.0 / (double)W; /* b / a(1) */
+    for (int n = 0; n < T; n++) {
+        double acc = 0.0;
+        for (int k = W - 1; k >= 1; k--) {   /* oldest first: z_{W-1} inwards to z_1 */
+            double p = (n - k >= 0) ? c * x[n - k] : 0.0;
+            acc = p + acc;
+        }
+        y[n] = c * x[n] + acc;
+    }
+}
+
+/* DF-II-T pass of an nb-tap FIR with equal taps c over e[0..n), initial state zi * e[0]; out may alias nothing */
+static void fir_df2t_zi(int n, const double *e, int nb, double c, const double *zi, double *out)
+{
+    double z[PRE_MAX_TAPS];
+    for (int i = 0; i < nb - 1; i++) z[i] = zi[i] * e[0];
+    for (int t = 0; t < n; t++) {
+        const double x = e[t];
+        const double y = (nb > 1) ? c * x + z[0] : c * x;
+        for (int i = 0; i < nb - 2; i++) z[i] = c * x + z[i + 1];
+        if (nb > 1) z[nb - 2] = c * x;
+        out[t] = y;
+    }
+}
+
+/* y = filtfilt(ones(1, W), W, x); returns 0, or -1 when T <= 3 (W - 1) ('Data length must be larger than ...') */
+static int zero_phase_ma(int T, const double *x, int W, double *y, double *scratch /* 2 * (T + 6 (W - 1)) */)
+{
+    const int nfact = (3 * (W - 1) > 1) ? 3 * (W - 1) : 1;
+    if (T <= nfact || W > PRE_MAX_TAPS) return -1;
+    const double c = 1.0 / (double)W;
+    double zi[PRE_MAX_TAPS];
+    if (W > 1) {
+        zi[W - 2] = c;
+        for (int i = W - 3; i >= 0; i--) zi[i] = c + zi[i + 1];
+    }
+    const int n = T + 2 * nfact;
+    double *e = scratch, *f = scratch + n;
+    for (int i = 0; i < nfact; i++) e[i] = 2 * x[0] - x[nfact - i];
+    for (int i = 0; i < T; i++) e[nfact + i] = x[i];
+    for (int i = 0; i < nfact; i++) e[nfact + T + i] = 2 * x[T - 1] - x[T - 2 - i];
+    fir_df2t_zi(n, e, W, c, zi, f);
+    for (int i = 0; i < n; i++) e[i] = f[n - 1 - i];
+    fir_df2t_zi(n, e, W, c, zi, f);
+    for (int i = 0; i < T; i++) y[i] = f[n - 1 - (nfact + i)];
+    return 0;
+}
+
+/* diff([c(1); c]), clamp negatives, fill a missing last day with the last valid one, other NaNs -> 0  (:166-178) */
+static void refine_counts(int T, const double *cum, double *out)
+{
+    int last_valid = -1;
+    for (int t = 0; t < T; t++) {
+        double d = cum[t] - cum[t > 0 ? t - 1 : 0];
+        if (d < 0) d = 0;                       /* NaN < 0 is false */
+        out[t] = d;
+        if (!isnan(d)) last_valid = t;
+    }
+    if (isnan(out[T - 1]) && last_valid >= 0) out[T - 1] = out[last_valid];
+    for (int t = 0; t < T; t++)
+        if (isnan(out[t])) out[t] = 0.0;
+}
+
+/* One region.  cases/deaths: cumulative confirmed counts [T] (deaths may be NULL).  Outputs (each may be NULL):
+ * new_refined, new_smoothed, zero_lag, x_new (= smoothed / N), x_total (= cumsum(smoothed) / N), R_v, fatality [T];
+ * *I0.  Returns 0, ORC_ERR_BAD_ARG for W out of range, T < 2 (:168) or T too short for filtfilt. */
+int orc_preprocess_region(int T, const double *cases, const double *deaths, double N_population, int W,
+                          double min_cases, int first_num_days, double *new_refined, double *new_smoothed,
+                          double *zero_lag, double *x_new, double *x_total, double *R_v, double *fatality, double *I0)
+{
+    if (W < 1 || W > PRE_MAX_TAPS || T < 2) return ORC_ERR_BAD_ARG;
+    const int W2 = (int)floor((double)W / 2 + 0.5);          /* MATLAB round(): halves away from zero */
+    double *ref = (double *)malloc(sizeof(double) * (size_t)T * 4), *sm = ref + T, *zl = sm + T, *cs = zl + T;
+    double *scratch = (double *)malloc(sizeof(double) * 2 * ((size_t)T + 6 * PRE_MAX_TAPS));
+    int rc = ORC_OK;
+    refine_counts(T, cases, ref);
+    causal_ma(T, ref, W, sm);                                /* :173 */
+    if (zero_phase_ma(T, ref, W2 < 1 ? 1 : W2, zl, scratch) != 0) rc = ORC_ERR_BAD_ARG;   /* :174 */
+    if (rc == ORC_OK) {
+        double run = 0.0;
+        for (int t = 0; t < T; t++) {
+            run = (t == 0) ? sm[0] : run + sm[t];            /* cumsum :178 */
+            cs[t] = run;
+            if (new_refined) new_refined[t] = ref[t];
+            if (new_smoothed) new_smoothed[t] = sm[t];
+            if (zero_lag) zero_lag[t] = zl[t];
+            if (x_new) x_new[t] = sm[t] / N_population;      /* :175 */
+            if (x_total) x_total[t] = run / N_population;    /* :180 */
+            if (R_v) { const double d = (zl[t] - ref[t]) / N_population; R_v[t] = 0.1 * (d * d); }   /* :240 */
+        }
+        if (I0) {                                            /* :201-202 */
+            double s = 0.0; int cnt = 0;
+            for (int t = 0; t < T && cnt < first_num_days; t++)
+                if (sm[t] > 0) { s = (cnt == 0) ? sm[t] : s + sm[t]; cnt++; }
+            const double mean = cnt ? s / cnt : NAN;
+            *I0 = fmax(min_cases, mean);
+        }
+        if (fatality && deaths) {                            /* :183-197 */
+            double *dr = ref, *ds = zl;                      /* reuse */
+            refine_counts(T, deaths, dr);
+            causal_ma(T, dr, W, ds);
+            double drun = 0.0;
+            for (int t = 0; t < T; t++) {
+                drun = (t == 0) ? ds[0] : drun + ds[t];
+                double fr = drun / cs[t];
+                fatality[t] = isnan(fr) ? 0.0 : fr;
+            }
+        }
+    }
+    free(ref); free(scratch);
+    return rc;
+}
+
+/* Tools/TrainPredictPrescribeNPI.m:142-150: carry the previous day's level over N/A days, leading N/A -> 0.
+ * ip: T x n_npi column-major (days down the rows, as read from the table) is NOT assumed here: ip[t * n_npi + j]. */
+void orc_npi_fill(int T, int n_npi, const double *ip, double *out)
+{
+    for (int j = 0; j < n_npi; j++) {
+        for (int t = 0; t < T; t++) {
+            double v = ip[(size_t)t * n_npi + j];
+            if (t > 0 && isnan(v) && !isnan(out[(size_t)(t - 1) * n_npi + j])) v = out[(size_t)(t - 1) * n_npi + j];
+            out[(size_t)t * n_npi + j] = v;
+        }
+        for (int t = 0; t < T; t++)
+            if (isnan(out[(size_t)t * n_npi + j])) out[(size_t)t * n_npi + j] = 0.0;
+    }
+}

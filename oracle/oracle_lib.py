@@ -295,3 +295,30 @@ def rt_expfit_batch(x, rp, L, order, x_series=None, n_threads=0):
     if rc != 0:
         raise OracleError(ERRORS.get(rc, str(rc)))
     return out
+
+
+PRE_OUT = ("new_refined", "new_smoothed", "zero_lag", "x_new", "x_total", "R_v", "fatality")
+
+
+def preprocess_region(cases, deaths, N_population, W=7, min_cases=1.0, first_num_days=7):
+    """Tools/TrainPredictPrescribeNPI.m:152-198,201-202,240 for one region through the C oracle."""
+    c = _f(cases); T = c.shape[0]
+    d = None if deaths is None else _f(deaths)
+    out = {n: np.zeros(T) for n in PRE_OUT}
+    I0 = C.c_double(0.0)
+    rc = lib().orc_preprocess_region(C.c_int(T), _dp(c), _dp(d), C.c_double(float(N_population)), C.c_int(int(W)),
+                                     C.c_double(float(min_cases)), C.c_int(int(first_num_days)),
+                                     *[_dp(out[n]) for n in PRE_OUT], C.byref(I0))
+    if rc != 0:
+        raise OracleError(ERRORS.get(rc, str(rc)))
+    out["I0"] = I0.value
+    if deaths is None:
+        del out["fatality"]
+    return out
+
+
+def npi_fill(ip):
+    """ip [T, n_npi] with NaN for N/A -> forward-filled copy (TrainPredictPrescribeNPI.m:142-150)."""
+    a = _f(ip); out = np.zeros_like(a)
+    lib().orc_npi_fill(C.c_int(a.shape[0]), C.c_int(a.shape[1]), _dp(a), _dp(out))
+    return out

@@ -380,3 +380,40 @@ def test_rt_expfit_known_answers():
     assert np.array_equal(o["S_PLUS"], o["S_MINUS"]) and not o["innovations"].any() and not o["K_GAIN"].any()
     with pytest.raises(olib.OracleError, match="Undefined order"):
         olib.rt_expfit(*args[:-1], 3)
+
+
+# ---------------------------------------------------------------- per-region preprocessing (8 f2)
+def test_preprocessing_c_oracle_matches_scipy_restatement():
+    """TrainPredictPrescribeNPI.m:142-198,201-202,240: the C restatement of filter / filtfilt against an independent
+    reading built on scipy.signal.lfilter / filtfilt (same published definitions), on defective synthetic columns."""
+    raw = synth.make_raw_counts(12, 150, seed=3)
+    for W in (7, 1, 2, 3, 10):
+        for r in (0, 5, 10, 11):
+            a = olib.preprocess_region(raw["cases"][:, r], raw["deaths"][:, r], raw["population"][r], W=W, min_cases=1.0)
+            b = enp.preprocess_region(raw["cases"][:, r], raw["deaths"][:, r], raw["population"][r], W=W, min_cases=1.0)
+            for k in b:
+                assert H.rel_err(np.asarray(a[k]), np.asarray(b[k])) <= 1e-13, (W, r, k)
+    ip = np.ascontiguousarray(raw["ip"][:, :, 4])
+    assert np.array_equal(olib.npi_fill(ip), enp.npi_fill(ip))
+
+
+def test_preprocessing_known_answers():
+    T = 40
+    cum = np.cumsum(np.full(T, 70.0))                      # 70 new cases every day
+    o = olib.preprocess_region(cum, None, 1e6, W=7, min_cases=1.0, first_num_days=7)
+    assert o["new_refined"][0] == 0 and (o["new_refined"][1:] == 70).all()          # diff([c(1); c])
+    assert np.allclose(o["new_smoothed"][7:], 70.0, rtol=1e-15) and abs(o["new_smoothed"][1] - 10.0) < 1e-12
+    assert np.allclose(o["zero_lag"][6:-1], 70.0, rtol=1e-14)                        # zero phase, no edge transient
+    assert np.allclose(o["x_total"], np.cumsum(o["new_smoothed"]) / 1e6, rtol=1e-15)
+    assert np.allclose(o["R_v"][6:-1], 0.0, atol=1e-30)
+    assert abs(o["I0"] - np.mean(o["new_smoothed"][1:8])) < 1e-12
+    cum2 = cum.copy(); cum2[20] -= 500; cum2[-1] = np.nan; cum2[10] = np.nan
+    o2 = olib.preprocess_region(cum2, None, 1e6)
+    assert o2["new_refined"][20] == 0 and o2["new_refined"][21] == 570               # negative jump clamped
+    assert o2["new_refined"][10] == 0 and o2["new_refined"][11] == 0                 # NaN day and the day after it
+    assert o2["new_refined"][-1] == o2["new_refined"][-2] == 70                      # missing last day filled
+    assert olib.preprocess_region(np.full(T, np.nan), None, 1e6)["I0"] == 1.0        # no data: I0 = min_cases
+    with pytest.raises(olib.OracleError):
+        olib.preprocess_region(cum[:9], None, 1e6)                                   # filtfilt needs > 9 samples (W2 = 4)
+    ip = np.array([[np.nan, 1.0], [np.nan, np.nan], [2.0, np.nan], [np.nan, 3.0]])
+    assert np.array_equal(olib.npi_fill(ip), [[0, 1], [0, 1], [2, 1], [2, 3]])
