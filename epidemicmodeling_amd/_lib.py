@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_calib_copy_f64_device",
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
-    "epi_preprocess_workspace_bytes", "epi_preprocess_device",
+    "epi_preprocess_workspace_bytes", "epi_preprocess_device", "epi_nnls_affine_fit_device",
 ]
 
 
@@ -77,6 +77,10 @@ PRE_OUT_NAMES = ("new_refined", "new_smoothed", "zero_lag", "x_new", "x_total", 
 
 class PreOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in PRE_OUT_NAMES]
+
+
+class NnlsDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "S", "D", "n", "max_iters")]
 
 
 _lib = None
@@ -149,6 +153,8 @@ def lib():
         h.epi_preprocess_device.restype = C.c_int
         h.epi_preprocess_device.argtypes = [C.POINTER(PreDesc)] + [C.c_void_p] * 4 + [C.POINTER(PreOutputs), C.c_void_p,
                                                                                         C.c_size_t, C.c_void_p, C.c_char_p]
+        h.epi_nnls_affine_fit_device.restype = C.c_int
+        h.epi_nnls_affine_fit_device.argtypes = [C.POINTER(NnlsDesc)] + [C.c_void_p] * 7 + [C.c_void_p, C.c_char_p]
         h.epi_calib_copy_f64_device.restype = C.c_int
         h.epi_calib_copy_f64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p]
         if h.epi_abi_version() != 1:

@@ -274,6 +274,28 @@ def preprocess(cases, population, deaths=None, ip=None, W=7, min_cases=1.0, firs
     return out
 
 
+def nnls_affine_fit(X, y, max_iters=100, device="cuda:0"):
+    """Regression between the EKF rounds on the device (Tools/TrainPredictPrescribeNPI.m:251-276, 'NONNEGATIVELS').
+    X [D, n, S] = NPI_MAXES - InterventionPlans over the regression window, y [D, S] = smoothed alpha.
+    Returns dict of torch tensors a [n, S], b [S], min_err [S], iters [S], flag [S]."""
+    dev = torch.device(device)
+    t = lambda v: v if isinstance(v, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float64).to(dev)
+    X, y = t(X).contiguous(), t(y).contiguous()
+    D, n, S = X.shape
+    d = _lib.NnlsDesc()
+    d.abi_version, d.S, d.D, d.n, d.max_iters = 1, S, D, n, int(max_iters)
+    out = {"a": torch.empty((n, S), dtype=torch.float64, device=dev), "b": torch.empty((S,), dtype=torch.float64, device=dev),
+           "min_err": torch.empty((S,), dtype=torch.float64, device=dev),
+           "iters": torch.empty((S,), dtype=torch.int32, device=dev), "flag": torch.empty((S,), dtype=torch.int32, device=dev)}
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_nnls_affine_fit_device(C.byref(d), _ptr(X), _ptr(y), _ptr(out["a"]), _ptr(out["b"]),
+                                               _ptr(out["min_err"]), _ptr(out["iters"]), _ptr(out["flag"]),
+                                               C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return out
+
+
 RT_OUT_ROWS = {"S_MINUS": 2, "S_PLUS": 2, "P_MINUS": 4, "P_PLUS": 4, "K_GAIN": 2, "S_SMOOTH": 2, "P_SMOOTH": 4,
                "innovations": 0, "rho": 0}
 

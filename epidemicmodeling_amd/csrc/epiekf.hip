@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
 #include "scenario_kernels.hpp"
 #include "rt_expfit.hpp"
 #include "preprocess.hpp"
+#include "nnls.hpp"
 
 struct SeirpRates { double ae, ai, kappa, rho, beta, mu, gamma; };
 EPI_DEV void seirp_rhs(const SeirpRates &r, const double (&y)[5], double (&f)[5])
@@ -1308,6 +1309,24 @@ int epi_preprocess_device(const epi_pre_desc *d, const double *cases, const doub
         hipLaunchKernelGGL(npi_fill, dim3((cols + 255) / 256), dim3(256), 0, st, d->T, cols, ip, out->ip_filled);
         if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "npi_fill launch");
     }
+    return EPI_OK;
+}
+
+int epi_nnls_affine_fit_device(const epi_nnls_desc *d, const double *X, const double *y, double *a, double *b,
+                               double *min_err, int32_t *iters, int32_t *flag, void *stream, char *err)
+{
+    if (!d || d->abi_version != EPIEKF_ABI_VERSION || d->S < 1 || d->D < 1 || d->n < 1 || d->n > kNnMax || d->max_iters < 0 ||
+        !X || !y || !a) {
+        set_err(err, "bad NNLS descriptor"); return EPI_ERR_BAD_ARG;
+    }
+    const size_t shmem = ((size_t)kNnDoubles * sizeof(double) + (size_t)kNnInts * sizeof(int)) * kNnLanes;
+    hipError_t e = hipFuncSetAttribute((const void *)nnls_affine_fit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return hip_fail(err, e, "hipFuncSetAttribute");
+    NnArgs g{};
+    g.S = d->S; g.D = d->D; g.n = d->n; g.max_iters = d->max_iters;
+    g.X = X; g.y = y; g.a = a; g.b = b; g.min_err = min_err; g.iters = iters; g.flag = flag;
+    hipLaunchKernelGGL(nnls_affine_fit, dim3((d->S + kNnLanes - 1) / kNnLanes), dim3(kNnLanes), shmem, (hipStream_t)stream, g);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "nnls_affine_fit launch");
     return EPI_OK;
 }
 

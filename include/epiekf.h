@@ -295,6 +295,22 @@ int epi_preprocess_device(const epi_pre_desc *d, const double *cases, const doub
                           const double *ip, const epi_pre_outputs *out, void *workspace, size_t workspace_bytes,
                           void *stream, char *err);
 
+/* ---- regression between the EKF rounds (Tools/TrainPredictPrescribeNPI.m:251-276, 'NONNEGATIVELS') ----
+ * For every region:  reg_coef_a = lsqnonneg(X, y); reg_coef_b = 0; then the loop :266-276 (at most max_iters = 100
+ * passes: coef_temp = lsqnonneg(X, y - reg_coef_b), coef0_temp = mean(y - X*reg_coef_a), accepted while the squared
+ * error decreases).  X [D][n][S] = NPI_MAXES - InterventionPlans over the regression window, y [D][S] = the smoothed
+ * alpha estimate; outputs a [n][S], b [S], min_err [S] (may be NULL), iters [S] (accepted passes, may be NULL),
+ * flag [S] (lsqnonneg exit flag of the first solve: 1, or 0 when its inner loop hit 3n iterations; may be NULL).
+ * lsqnonneg = Lawson & Hanson's active-set algorithm with MATLAB's tolerance 10*eps*norm(X,1)*length(X), evaluated on
+ * the normal equations with a diagonally pivoted Cholesky for the passive-set solves.  1 <= n <= 12. */
+typedef struct epi_nnls_desc {
+    int32_t abi_version;
+    int32_t S, D, n;
+    int32_t max_iters;   /* NONNEGATIVELS_IRERATIONS (100 in the reference) */
+} epi_nnls_desc;
+int epi_nnls_affine_fit_device(const epi_nnls_desc *d, const double *X, const double *y, double *a, double *b,
+                               double *min_err, int32_t *iters, int32_t *flag, void *stream, char *err);
+
 /* SEIRP.m:1-32 / SEIRPSaturatedResource.m:1-38 batched: par [K][7][B] per-step parameter arrays in the
  * order alpha_e, alpha_i, kappa, rho, beta, mu, gamma (or constant-in-time: par [1][7][B], par_steps=1);
  * init [5][B] = s0,e0,i0,r0,p0; out [K][5][B].  saturated != 0: sat [6][B] = beta_0,beta_s,mu_0,mu_s,

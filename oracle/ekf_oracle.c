@@ -1290,3 +1290,161 @@ void orc_npi_fill(int T, int n_npi, const double *ip, double *out)
             if (isnan(out[(size_t)t * n_npi + j])) out[(size_t)t * n_npi + j] = 0.0;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Regression between the EKF rounds: Tools/TrainPredictPrescribeNPI.m:251-276,
+ * REGRESSION_TYPE = 'NONNEGATIVELS':  alpha(t) ~ a' (NPI_MAXES - u(t)) + b,  a >= 0.
+ *
+ * lsqnonneg is a MATLAB built-in that is not in the reference checkout; it implements Lawson & Hanson's
+ * active-set NNLS (1974) with tol = 10*eps*norm(C,1)*length(C) and itmax = 3n.  Restated here on the normal
+ * equations (G = C'C, h = C'd): the active-set logic is Lawson-Hanson's verbatim, the passive-set least-squares
+ * solve C(:,P)\d is a Cholesky factorisation of G(P,P) with diagonal pivoting -- in exact arithmetic the same pivot
+ * order and the same basic solution (dependent columns 0) as the pivoted QR behind MATLAB's backslash.  A pivot
+ * below 100*n*eps*max(diag) ends the factorisation (rank decision on the squared scale of the Gram matrix).
+ * ---------------------------------------------------------------------------------------------- */
+#define NN_MAX 12
+
+/* z(P) = argmin ||C(:,P) z - d||, z(~P) = 0, from G and h */
+static void nnls_solve_passive(int n, const double *G, const double *h, const int *inP, double *z)
+{
+    int idx[NN_MAX], k = 0;
+    double A[NN_MAX * NN_MAX], b[NN_MAX], y[NN_MAX];
+    for (int j = 0; j < n; j++) { z[j] = 0.0; if (inP[j]) idx[k++] = j; }
+    if (k == 0) return;
+    for (int i = 0; i < k; i++) {
+        b[i] = h[idx[i]];
+        for (int j = 0; j < k; j++) A[i + NN_MAX * j] = G[idx[i] + n * idx[j]];
+    }
+    double dmax = 0.0;
+    for (int i = 0; i < k; i++) dmax = fmax(dmax, A[i + NN_MAX * i]);
+    const double ptol = 100.0 * n * DBL_EPS * dmax;
+    int rank = 0;
+    for (int i = 0; i < k; i++) {                        /* lower-triangular Cholesky with diagonal pivoting */
+        int p = i;
+        for (int j = i + 1; j < k; j++)
+            if (A[j + NN_MAX * j] > A[p + NN_MAX * p]) p = j;
+        if (!(A[p + NN_MAX * p] > ptol)) break;
+        if (p != i) {
+            for (int c = 0; c < k; c++) { double t = A[i + NN_MAX * c]; A[i + NN_MAX * c] = A[p + NN_MAX * c]; A[p + NN_MAX * c] = t; }
+            for (int r = 0; r < k; r++) { double t = A[r + NN_MAX * i]; A[r + NN_MAX * i] = A[r + NN_MAX * p]; A[r + NN_MAX * p] = t; }
+            { double t = b[i]; b[i] = b[p]; b[p] = t; }
+            { int t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
+        }
+        const double d = sqrt(A[i + NN_MAX * i]);
+        A[i + NN_MAX * i] = d;
+        for (int j = i + 1; j < k; j++) A[j + NN_MAX * i] = A[j + NN_MAX * i] / d;
+        for (int c = i + 1; c < k; c++)                  /* whole trailing block: stays exactly symmetric for the swaps */
+            for (int r = i + 1; r < k; r++) A[r + NN_MAX * c] = fma(-A[r + NN_MAX * i], A[c + NN_MAX * i], A[r + NN_MAX * c]);
+        rank = i + 1;
+    }
+    for (int i = 0; i < rank; i++) {                     /* L y = b */
+        double acc = b[i];
+        for (int j = 0; j < i; j++) acc = fma(-A[i + NN_MAX * j], y[j], acc);
+        y[i] = acc / A[i + NN_MAX * i];
+    }
+    for (int i = rank - 1; i >= 0; i--) {                /* L' z = y */
+        double acc = y[i];
+        for (int j = i + 1; j < rank; j++) acc = fma(-A[j + NN_MAX * i], y[j], acc);
+        y[i] = acc / A[i + NN_MAX * i];
+    }
+    for (int i = 0; i < rank; i++) z[idx[i]] = y[i];
+}
+
+/* x = lsqnonneg(C, d) given G = C'C (n x n column-major), h = C'd and tol.  Returns the exit flag (1, or 0 when the
+ * inner loop hit 3n iterations). */
+int orc_nnls_gram(int n, const double *G, const double *h, double tol, double *x)
+{
+    int inP[NN_MAX] = {0};
+    double w[NN_MAX], z[NN_MAX];
+    for (int j = 0; j < n; j++) { x[j] = 0.0; w[j] = h[j]; }   /* resid = d - C*0 */
+    int iter = 0;
+    const int itmax = 3 * n;
+    for (;;) {
+        int t = -1;
+        for (int j = 0; j < n; j++)
+            if (!inP[j] && w[j] > tol && (t < 0 || w[j] > w[t])) t = j;   /* any(Z) && any(w(Z) > tol); first max */
+        if (t < 0) return 1;
+        inP[t] = 1;
+        nnls_solve_passive(n, G, h, inP, z);
+        for (;;) {
+            int any = 0;
+            for (int j = 0; j < n; j++) any |= (inP[j] && z[j] <= 0.0);
+            if (!any) break;
+            if (++iter > itmax) { for (int j = 0; j < n; j++) x[j] = z[j]; return 0; }
+            double alpha = INFINITY;
+            for (int j = 0; j < n; j++)
+                if (inP[j] && z[j] <= 0.0) alpha = fmin(alpha, x[j] / (x[j] - z[j]));
+            for (int j = 0; j < n; j++) x[j] = x[j] + alpha * (z[j] - x[j]);
+            for (int j = 0; j < n; j++)
+                if (inP[j] && fabs(x[j]) < tol) inP[j] = 0;
+            nnls_solve_passive(n, G, h, inP, z);
+        }
+        for (int j = 0; j < n; j++) x[j] = z[j];
+        for (int i = 0; i < n; i++) {                     /* w = C'(d - C x) = h - G x */
+            double acc = G[i] * x[0];
+            for (int j = 1; j < n; j++) acc = fma(G[i + n * j], x[j], acc);
+            w[i] = h[i] - acc;
+        }
+    }
+}
+
+/* G, h, tol of lsqnonneg(X, y - shift) for X [D x n] row t at X[t * n + j] */
+static void nnls_normal_equations(int D, int n, const double *X, const double *y, double shift, double *G, double *h, double *tol)
+{
+    for (int i = 0; i < n; i++) {
+        double cs = 0.0;
+        for (int t = 0; t < D; t++) cs = cs + fabs(X[(size_t)t * n + i]);
+        if (i == 0 || cs > *tol) *tol = cs;                /* norm(C, 1) */
+        double hv = 0.0;
+        for (int t = 0; t < D; t++) hv = fma(X[(size_t)t * n + i], y[t] - shift, hv);
+        h[i] = hv;
+        for (int j = 0; j <= i; j++) {
+            double g = 0.0;
+            for (int t = 0; t < D; t++) g = fma(X[(size_t)t * n + i], X[(size_t)t * n + j], g);
+            G[i + n * j] = g; G[j + n * i] = g;
+        }
+    }
+    *tol = 10.0 * DBL_EPS * (*tol) * (double)(D > n ? D : n);   /* 10*eps*norm(C,1)*length(C) */
+}
+
+/* TrainPredictPrescribeNPI.m:262-276 for one region: X [D][n] (row-major: day, NPI), y [D].  Outputs a [n], *b, *min_err,
+ * *iters (passes of the :266 loop that were accepted). */
+int orc_nnls_affine_fit(int D, int n, const double *X, const double *y, int max_iters, double *a, double *b,
+                        double *min_err, int *iters)
+{
+    if (n < 1 || n > NN_MAX || D < 1) return ORC_ERR_BAD_ARG;
+    double G[NN_MAX * NN_MAX], h[NN_MAX], tol = 0.0, coef[NN_MAX];
+    nnls_normal_equations(D, n, X, y, 0.0, G, h, &tol);
+    orc_nnls_gram(n, G, h, tol, a);                          /* :263 */
+    double bb = 0.0, err = 0.0;
+    for (int t = 0; t < D; t++) {
+        double xa = X[(size_t)t * n] * a[0];
+        for (int j = 1; j < n; j++) xa = fma(X[(size_t)t * n + j], a[j], xa);
+        const double r = y[t] - xa;
+        err = (t == 0) ? r * r : err + r * r;                /* :265 */
+    }
+    int acc = 0;
+    for (int jj = 0; jj < max_iters; jj++) {                 /* :266-276 */
+        nnls_normal_equations(D, n, X, y, bb, G, h, &tol);
+        orc_nnls_gram(n, G, h, tol, coef);                   /* lsqnonneg(X, y - reg_coef_b) */
+        double s = 0.0;
+        for (int t = 0; t < D; t++) {                        /* mean(y - X*reg_coef_a): the CURRENT reg_coef_a */
+            double xa = X[(size_t)t * n] * a[0];
+            for (int j = 1; j < n; j++) xa = fma(X[(size_t)t * n + j], a[j], xa);
+            const double r = y[t] - xa;
+            s = (t == 0) ? r : s + r;
+        }
+        const double c0 = s / D;
+        double e = 0.0;
+        for (int t = 0; t < D; t++) {
+            double xa = X[(size_t)t * n] * a[0];
+            for (int j = 1; j < n; j++) xa = fma(X[(size_t)t * n + j], a[j], xa);
+            const double r = (y[t] - xa) - c0;
+            e = (t == 0) ? r * r : e + r * r;
+        }
+        if (e < err) { for (int j = 0; j < n; j++) a[j] = coef[j]; bb = c0; err = e; acc++; }
+        else break;
+    }
+    *b = bb; *min_err = err; if (iters) *iters = acc;
+    return ORC_OK;
+}

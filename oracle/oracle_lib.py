@@ -322,3 +322,27 @@ def npi_fill(ip):
     a = _f(ip); out = np.zeros_like(a)
     lib().orc_npi_fill(C.c_int(a.shape[0]), C.c_int(a.shape[1]), _dp(a), _dp(out))
     return out
+
+
+def nnls_affine_fit(X, y, max_iters=100):
+    """TrainPredictPrescribeNPI.m:262-276 (REGRESSION_TYPE 'NONNEGATIVELS') for one region: X [D, n], y [D] ->
+    dict a [n], b, min_err, iters."""
+    X = _f(X); y = _f(y)
+    D, n = X.shape
+    a = np.zeros(n); b = C.c_double(); e = C.c_double(); it = C.c_int()
+    rc = lib().orc_nnls_affine_fit(C.c_int(D), C.c_int(n), _dp(X), _dp(y), C.c_int(int(max_iters)), _dp(a), C.byref(b),
+                                   C.byref(e), C.byref(it))
+    if rc != 0:
+        raise OracleError(ERRORS.get(rc, str(rc)))
+    return {"a": a, "b": b.value, "min_err": e.value, "iters": it.value}
+
+
+def nnls(Cm, d):
+    """x = lsqnonneg(C, d) through the oracle's normal-equation Lawson-Hanson."""
+    Cm = _f(Cm); d = _f(d)
+    D, n = Cm.shape
+    G = np.asfortranarray(Cm.T @ Cm); h = np.ascontiguousarray(Cm.T @ d)
+    tol = 10 * np.finfo(float).eps * np.abs(Cm).sum(axis=0).max() * max(D, n)
+    x = np.zeros(n)
+    lib().orc_nnls_gram(C.c_int(n), _dp(G), _dp(h), C.c_double(tol), _dp(x))
+    return x

@@ -142,3 +142,28 @@ def with_time_varying_q(w, seed=0):
     scale = 1.0 + 0.5 * np.sin(np.arange(w.T) / 7.0)[:, None, None] + 0.1 * rng.random((w.T, 1, w.B))
     w2.Q = np.ascontiguousarray(w.Q[None, :, :] * scale)
     return w2
+
+
+def make_regression_problem(S=40, D=120, n=12, seed=0):
+    """Regression windows like TrainPredictPrescribeNPI.m:251-253: X = NPI_MAXES - InterventionPlans (small integers,
+    step-like in time, some NPIs never changed => constant / collinear columns, some always at the maximum => zero
+    columns), y = smoothed alpha.  Returns X [D, n, S], y [D, S]."""
+    from epidemicmodeling_amd import synth
+    rng = np.random.default_rng(seed)
+    umax = synth.IP_MAXES[:n]
+    lvl = np.floor(rng.random((D, n, S)) * (umax[None, :, None] + 1))
+    keep = rng.random((D, n, S)) < 0.04
+    keep[0] = True
+    idx = np.maximum.accumulate(np.where(keep, np.arange(D)[:, None, None], 0), axis=0)
+    ip = np.take_along_axis(lvl, idx, axis=0)                    # piecewise-constant policies
+    if n > 2:
+        ip[:, 2, ::3] = 1.0                                       # never changed
+    if n > 5:
+        ip[:, 5, ::3] = 2.0                                       # never changed (collinear with the one above)
+    if n > 7:
+        ip[:, 7, ::4] = umax[7]                                   # always at the maximum: zero column of X
+    X = umax[None, :, None] - ip
+    a_true = np.maximum(rng.normal(0.0, 0.02, (n, S)), 0.0)
+    y = np.einsum("dns,ns->ds", X, a_true) + 0.08 + 0.004 * rng.standard_normal((D, S))
+    y[:, 1::7] -= 0.2                                             # regions whose mean residual is negative
+    return np.ascontiguousarray(X), np.ascontiguousarray(y)

@@ -417,3 +417,42 @@ def test_preprocessing_known_answers():
         olib.preprocess_region(cum[:9], None, 1e6)                                   # filtfilt needs > 9 samples (W2 = 4)
     ip = np.array([[np.nan, 1.0], [np.nan, np.nan], [2.0, np.nan], [np.nan, 3.0]])
     assert np.array_equal(olib.npi_fill(ip), [[0, 1], [0, 1], [2, 1], [2, 3]])
+
+
+# ---------------------------------------------------------------- NNLS between the EKF rounds (8 f4)
+def test_nnls_matches_scipy_lawson_hanson():
+    """The oracle's lsqnonneg (Lawson-Hanson on the normal equations, pivoted Cholesky) against SciPy's Lawson-Hanson
+    (QR-based): same solution on full-rank problems, same residual and a non-negative basic solution on rank-deficient
+    ones (constant and zero columns)."""
+    from scipy.optimize import nnls as sp_nnls
+    X, y = H.make_regression_problem(24, 150, 12, seed=5)
+    for s in range(24):
+        Xs, ys = np.ascontiguousarray(X[:, :, s]), np.ascontiguousarray(y[:, s])
+        a = olib.nnls(Xs, ys)
+        ref, rn = sp_nnls(Xs, ys)
+        assert (a >= 0).all()
+        assert abs(np.linalg.norm(Xs @ a - ys) - rn) <= 1e-12 * max(rn, 1.0), s
+        if np.linalg.matrix_rank(Xs) == 12:
+            assert np.abs(a - ref).max() <= 1e-10, s
+    # textbook cases
+    assert np.array_equal(olib.nnls(np.eye(3), np.array([1.0, -2.0, 3.0])), [1.0, 0.0, 3.0])
+    assert np.array_equal(olib.nnls(np.ones((5, 2)), -np.ones(5)), [0.0, 0.0])
+
+
+def test_nnls_affine_fit_loop_semantics():
+    """TrainPredictPrescribeNPI.m:262-276: the loop evaluates the intercept with the CURRENT reg_coef_a, so it ends
+    after one accepted pass with a = lsqnonneg(X, y), b = mean(y - X a) -- or with b = 0 when that does not lower the
+    squared error."""
+    X, y = H.make_regression_problem(10, 100, 12, seed=2)
+    for s in range(10):
+        Xs, ys = np.ascontiguousarray(X[:, :, s]), np.ascontiguousarray(y[:, s])
+        f = olib.nnls_affine_fit(Xs, ys)
+        a0 = olib.nnls(Xs, ys)
+        assert np.abs(f["a"] - a0).max() <= 1e-12 and f["iters"] in (0, 1)
+        r = ys - Xs @ f["a"]
+        if f["iters"] == 1:
+            assert abs(f["b"] - r.mean()) <= 1e-14 and abs(f["min_err"] - ((r - r.mean()) ** 2).sum()) <= 1e-12
+        else:
+            assert f["b"] == 0.0
+    f0 = olib.nnls_affine_fit(Xs, ys, max_iters=0)
+    assert f0["b"] == 0.0 and f0["iters"] == 0
