@@ -400,7 +400,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         // s(k+1|k) and P(k+1|k) are NOT read back: they are recomputed from the stored s(k|k), P(k|k), u(:,k) with
         // the forward kernel's own functions (:155-164) -- bit-identical, and 27 fewer loads per step for a kernel
         // that is bound by the number of memory operations a CU can issue
-        double A[M * M], Sm1[M], Pm1[NS];
+        double A[M * M], Sm1[M];
         state_jacobians<M, FLIP>(p, cur.u, cur.Sp, A);         // :206 (and :157 of the forward pass)
         {
             double u_app[kNpi];
@@ -409,7 +409,6 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             nlin_state_update<M, FLIP>(p, a.mf, u_app, cur.Sp, Sm1);
             state_hard_margins<M>(p, Sm1);
         }
-        predict_cov_sym<M>(A, cur.Pp, Qd, Pm1);
         double J[M * M];
         int rank = -1;
         if (cur.rk < 0) {                                      // non-finite P_MINUS guard :211-213
@@ -464,9 +463,11 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             // P_SMOOTH(k) = sym(P+ - (J D) J'),  D = P_MINUS(k+1) - P_SMOOTH(k+1)   :223-226
             // rows of J D are consumed one at a time and paired entries are averaged as soon as both exist
             // (see ekf_fwd_sym)
+            // (P(k+1|k) is formed only now, after X has been consumed by J: the two are never live together)
             double Dsym[NS];
+            predict_cov_sym<M>(A, cur.Pp, Qd, Dsym);
 #pragma unroll
-            for (int e = 0; e < NS; e++) Dsym[e] = Pm1[e] - Ps[e];
+            for (int e = 0; e < NS; e++) Dsym[e] = Dsym[e] - Ps[e];
             double F[M * M];
 #pragma unroll
             for (int i = 0; i < M; i++) {

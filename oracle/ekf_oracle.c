@@ -12,10 +12,16 @@
  *   Tools/NewCaseEKFEstimatorWithOptimalNPI.m:1-290 (+ MatlabCodeGenerator twin)
  *   Tools/SIalpha_Controlled.m, SI_Controlled.m, SEIRP.m,
  *   Tools/SEIRPSaturatedResource.m, Tools/NPICost.m
+ *   Tools/Rt_ExpFitEKF.m                            (whole file)
+ *   Tools/TrainPredictPrescribeNPI.m:142-198,201-202,240 (per-region preprocessing),
+ *       :251-276 (NNLS regression between the EKF rounds), :496-521 (random-NPI
+ *       scenarios), :624-633 (Pareto front and optimum)
  * MATLAB built-ins restated: pinv (symmetric argument: cyclic Jacobi
  * eigen-decomposition + tol = max(size)*eps(norm)), mrdivide for a square
  * right operand (LU with partial pivoting, LAPACK dgetf2/dgetrs operation
- * order), NaN-ignoring min/max (fmin/fmax), eps, squeeze.
+ * order), NaN-ignoring min/max (fmin/fmax), eps, squeeze; filter / filtfilt
+ * (Signal Processing Toolbox) and lsqnonneg from their published definitions --
+ * see the sections that use them.
  *
  * Matrix products are evaluated as MATLAB writes them, left to right.  Every
  * BLAS-class operation (matrix-matrix, matrix-vector and dot products -- what
