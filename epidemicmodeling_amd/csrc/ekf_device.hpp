@@ -49,6 +49,14 @@ struct VecLds {
     EPI_DEV double Umax(int k) const { return base[(2 * kNpi + k) * kWave]; }
     EPI_DEV double W(int k) const { return base[(3 * kNpi + k) * kWave]; }
 };
+struct VecLdsS {          // the same with a run-time lane stride (LDS sized by the lanes a workgroup actually uses)
+    const double *base;
+    int stride;
+    EPI_DEV double A(int k) const { return base[(0 * kNpi + k) * stride]; }
+    EPI_DEV double Umin(int k) const { return base[(1 * kNpi + k) * stride]; }
+    EPI_DEV double Umax(int k) const { return base[(2 * kNpi + k) * stride]; }
+    EPI_DEV double W(int k) const { return base[(3 * kNpi + k) * stride]; }
+};
 template <class V>
 struct LitePrm {
     double dt, beta, gamma, sigma, b, epsilon, slo, ilo, alpha_min, alpha_max;
@@ -107,7 +115,7 @@ EPI_DEV void load_prm(ChainPrm &p, const double *__restrict__ prm, int B, int c,
 // and has already been written.  Returns the sum newest -> oldest, added strictly in that order (the
 // reference's cat/sum order).  The LDS reads are issued ten at a time so that their latencies overlap; only
 // the additions are serial.
-EPI_DEV double ring_sum(const double *win, int head, int L, double newest)
+EPI_DEV double ring_sum(const double *win, int head, int L, double newest, int stride = kWave)
 {
     constexpr int BLK = 10;
     double sum = newest;
@@ -115,11 +123,11 @@ EPI_DEV double ring_sum(const double *win, int head, int L, double newest)
     for (; j + BLK <= L; j += BLK) {
         double v[BLK];
 #pragma unroll
-        for (int q = 0; q < BLK; q++) { idx = (idx + 1 == L) ? 0 : idx + 1; v[q] = win[idx * kWave]; }
+        for (int q = 0; q < BLK; q++) { idx = (idx + 1 == L) ? 0 : idx + 1; v[q] = win[idx * stride]; }
 #pragma unroll
         for (int q = 0; q < BLK; q++) sum = sum + v[q];
     }
-    for (; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sum = sum + win[idx * kWave]; }
+    for (; j < L; j++) { idx = (idx + 1 == L) ? 0 : idx + 1; sum = sum + win[idx * stride]; }
     return sum;
 }
 

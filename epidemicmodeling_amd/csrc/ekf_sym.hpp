@@ -91,6 +91,26 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
 #ifndef EPI_BWD_LB
 #define EPI_BWD_LB kWave
 #endif
+constexpr int kPipeLanes = 40;   // lanes per workgroup of the LP = 1 forward variant
+// where the forward kernel keeps the model constants (see ekf_fwd_sym)
+template <int LP> struct PrmSelect { typedef ChainPrm type; };
+template <> struct PrmSelect<1> { typedef LitePrm<VecLdsS> type; };
+template <int M>
+EPI_DEV void init_prm(ChainPrm &p, const KArgs &a, int B, int c, double *, int) { load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero); }
+template <int M>
+EPI_DEV void init_prm(LitePrm<VecLdsS> &p, const KArgs &a, int B, int c, double *col, int stride)
+{
+    load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
+    p.v.base = col; p.v.stride = stride;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) {
+        col[(0 * kNpi + k) * stride] = a.prm[(size_t)(EPI_PRM_A + k) * B + c];
+        col[(1 * kNpi + k) * stride] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
+        col[(2 * kNpi + k) * stride] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
+        col[(3 * kNpi + k) * stride] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+    }
+}
+
 // P(k+1|k) = sym(A P(k|k) A' + Q), Q diagonal (GenericEKF.m:158-161), packed in and out.  One ROW at a time with
 // the structural zeros of A skipped: row i of T1 = A P is formed, consumed into row i of the full result G, and as
 // soon as both G(i,j) and G(j,i) exist they are averaged into the packed result.  Shared by ekf_fwd_sym and by
@@ -134,10 +154,17 @@ EPI_DEV void predict_cov_sym(const double (&A)[M * M], const double (&Pp)[M * (M
     }
 }
 
-template <int M, int FLIP>
+// LP = 0: the model constants live in VGPRs (ChainPrm), the windows use a 64-lane stride -- 408 VGPRs, one wave per
+//         SIMD, nothing else fits beside it.
+// LP = 1: the four 12-vectors of `params` live in LDS next to the windows and every LDS array is sized by the lanes the
+//         workgroup really uses (kPipeLanes = 40) -- 298 VGPRs and (3 L + 48) * 40 * 8 bytes of LDS, so that four such
+//         waves fit a CU AND an eks_pinv wave (194 VGPRs, no LDS) fits beside each of them: the pipelined launch
+//         (epi_batch_desc.chunks = -2) runs one half's eks_pinv grid in the issue slots the other half's forward waves
+//         leave idle.
+template <int M, int FLIP, int LP>
 __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
-    extern __shared__ double lds[];   // three sliding windows [3][L][64], one column per lane
+    extern __shared__ double lds[];   // three sliding windows [3][L][stride], one column per lane (+ [48][stride], LP)
     if (*dense_flag) return;          // ekf_fwd (dense) runs instead
     constexpr int NS = nsym<M>();
     const int lane = threadIdx.x;
@@ -147,8 +174,9 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
 
-    ChainPrm p;                       // one wave per SIMD: there is room for the 12-vectors in VGPRs
-    load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero);
+    constexpr int stride = LP ? kPipeLanes : kWave;   // compile-time: LDS offsets stay immediates
+    typename PrmSelect<LP>::type p;
+    init_prm<M>(p, a, B, c, lds + (size_t)3 * L * stride + lane, stride);
     const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
     const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
     const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
@@ -164,8 +192,8 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
 #pragma unroll
         for (int i = 0; i <= j; i++) Pm[sidx(i, j)] = a.Ps_init[(size_t)IXM(i, j) * B + c];
 
-    double *winMean = lds + lane, *winCov = lds + (size_t)L * kWave + lane, *winCovN = lds + (size_t)2 * L * kWave + lane;
-    for (int j = 0; j < L; j++) { winMean[j * kWave] = 0.0; winCov[j * kWave] = 0.0; winCovN[j * kWave] = 0.0; }
+    double *winMean = lds + lane, *winCov = lds + (size_t)L * stride + lane, *winCovN = lds + (size_t)2 * L * stride + lane;
+    for (int j = 0; j < L; j++) { winMean[j * stride] = 0.0; winCov[j * stride] = 0.0; winCovN[j * stride] = 0.0; }
     int head = 0;
     const bool fixed_R = (a.r_mode == 0);
     const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
@@ -285,18 +313,18 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         // innovation monitor (identical to ekf_fwd)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
         head = (head == 0) ? (L - 1) : (head - 1);
-        winMean[head * kWave] = innov;
-        const double sum = ring_sum(winMean, head, L, innov);
+        winMean[head * stride] = innov;
+        const double sum = ring_sum(winMean, head, L, innov, stride);
         const double mu = sum / (double)cnt;
         const double cc = (innov - mu) * (innov - mu);
         const double ccn = cc / (Rk + kEps);
-        winCov[head * kWave] = cc;
-        winCovN[head * kWave] = ccn;
-        const double sumN = ring_sum(winCovN, head, L, ccn);
+        winCov[head * stride] = cc;
+        winCovN[head * stride] = ccn;
+        const double sumN = ring_sum(winCovN, head, L, ccn, stride);
         if (a.rho) stg(a.rho + (size_t)t * B, voff, sumN / (double)cnt);
         if (fixed_R) {
             if (beta != 1.0 && valid && k < T - 1) {
-                const double sumC = ring_sum(winCov, head, L, cc);
+                const double sumC = ring_sum(winCov, head, L, cc, stride);
                 R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);
             } else {
                 R_next = R_v;

@@ -717,6 +717,26 @@ struct SideStreams {
 };
 static thread_local SideStreams g_side;   // helper streams of the calling thread (created on first use)
 
+// a helper stream of the LOWEST priority: its eks_pinv workgroups are placed after the forward kernel's (pipelined launch)
+struct LowPrioStream { hipStream_t stream = nullptr; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; int device = -1; };
+static thread_local LowPrioStream g_low;
+static hipError_t low_prio_stream(LowPrioStream **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (g_low.device != dev) { g_low = LowPrioStream(); g_low.device = dev; }
+    if (!g_low.stream) {
+        int lo = 0, hi = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&lo, &hi)) != hipSuccess) return e;   // lo = numerically largest = lowest
+        if ((e = hipStreamCreateWithPriority(&g_low.stream, hipStreamNonBlocking, lo)) != hipSuccess) return e;
+        for (auto &ev : g_low.ev)
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    *out = &g_low;
+    return hipSuccess;
+}
+
 static hipError_t side_streams(int n, SideStreams **out)
 {
     int dev = 0;
@@ -770,7 +790,12 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
     hipError_t e = hipSuccess;
     if (phase == 0 || phase == 1) {
         if (run_sym) {   // hint 0: both variants are enqueued, the one ekf_precheck did not select returns at once
-            hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
+            // narrow (balanced) waves: the variant with LDS-resident model constants and LDS sized by 40 lanes -- 298
+            // instead of 408 VGPRs (a third of the AGPR traffic), still four workgroups per CU
+            const size_t per_lane = ((size_t)3 * ka.L + 4 * kNpi) * sizeof(double);
+            const bool lp = M == 6 && ka.lw <= kPipeLanes && per_lane * kPipeLanes * 4 <= 160u * 1024u && !getenv("EPIEKF_NO_LP");
+            if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), per_lane * kPipeLanes, st, ka, ka.dense_flag);
+            else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (run_dense) {
@@ -807,7 +832,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
             if (e != hipSuccess) return e;
             if (GENERIC) {
-                e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP>,
+                e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP, 0>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
                 if (e != hipSuccess) return e;
             }
@@ -846,6 +871,41 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
             return hipStreamWaitEvent(st, ss->join[0], 0);
         }
         return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
+    }
+    if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1) {
+        // Pipelined halves.  The forward kernel of the second half and the eks_pinv grid of the first half are in flight
+        // together, and -- because this forward variant (LDS-resident model constants, LDS sized by the lanes used)
+        // needs 298 VGPRs and eks_pinv 194 -- they share SIMDs: the VALU-bound Jacobi runs in the issue slots the
+        // latency-bound filter waves leave idle.  The backward kernel (492 VGPRs) cannot share; it follows as one launch.
+        int dev = 0, cus = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        const size_t per_lane = ((size_t)3 * ka.L + 4 * kNpi) * sizeof(double);
+        const int lw = kPipeLanes;
+        const bool lds_ok = per_lane * lw * 4 <= 160u * 1024u;         // four forward workgroups per CU by LDS (L <= 26)
+        const int half = (ka.B / 2 + 7) / 8 * 8;
+        if (lds_ok && half > 0 && half < ka.B) {
+            LowPrioStream *lp = nullptr;
+            if ((e = low_prio_stream(&lp)) != hipSuccess) return e;
+            const size_t shm = per_lane * lw;
+            if (shm > 64u * 1024u &&
+                (e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess)
+                return e;
+            const int c0s[2] = {0, half}, cns[2] = {half, ka.B - half};
+            for (int h = 0; h < 2; h++) {
+                KArgs kc = ka;
+                kc.c0 = c0s[h]; kc.cn = cns[h]; kc.lw = lw;
+                hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3((kc.cn + lw - 1) / lw), dim3(kWave), shm, st, kc, kc.dense_flag);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if ((e = hipEventRecord(lp->ev[h], st)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(lp->stream, lp->ev[h], 0)) != hipSuccess) return e;
+                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((kc.cn + 255) / 256), (unsigned)(ka.T - 1)), dim3(256), 0, lp->stream, kc);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
+            if ((e = hipEventRecord(lp->ev[2], lp->stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(st, lp->ev[2], 0)) != hipSuccess) return e;
+            return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, 4, smooth, hint, shmem, st);
+        }
     }
     if (phase != 0 || chunks <= 1 || ka.B < chunks * kWave)
         return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
@@ -919,7 +979,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     // three fp64 windows of L samples per lane must fit the CU's 160 KiB LDS
     if (d->phase < 0 || d->phase > 4) { set_err(err, "phase must be 0..4"); return EPI_ERR_BAD_ARG; }
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
-    if (d->chunks < -1) { set_err(err, "chunks must be >= -1"); return EPI_ERR_BAD_ARG; }
+    if (d->chunks < -2) { set_err(err, "chunks must be >= -2"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
 }

@@ -123,7 +123,9 @@ typedef struct epi_batch_desc {
                              enqueued on its own helper stream, so that one chunk's (chain, step)-parallel
                              eks_pinv grid fills the SIMDs the other chunks' one-wave-per-SIMD sequential
                              kernels leave idle; 0/1: one chunk on the caller's stream; -1: "rounds + tail" (the
-                             waves beyond a whole number of one-wave-per-SIMD rounds form the second chunk) */
+                             waves beyond a whole number of one-wave-per-SIMD rounds form the second chunk);
+                             -2: "pipelined halves" (generic models, path_hint = 1): the second half's forward
+                             kernel and the first half's eks_pinv grid share the SIMDs */
 } epi_batch_desc;
 
 typedef struct epi_inputs {
