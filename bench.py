@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--eps", type=int, default=250)
     ap.add_argument("--t-hist", type=int, default=400)
     ap.add_argument("--horizon", type=int, default=120)
-    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg3", "cfg5"])
+    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg3", "cfg5", "newcase"])
     ap.add_argument("--outputs", default="all", choices=["all", "reduced"],
                     help="reduced = u_opt_smooth + S_SMOOTH only (what TrainPredictPrescribeNPI.m:460-493 consumes)")
     ap.add_argument("--chunks", type=int, default=0,
@@ -65,6 +65,10 @@ def make_workload(args, rank):
     if args.workload == "cfg4":
         w = synth.make_cfg4(args.regions, args.eps, args.t_hist, args.horizon, region_offset=rank * args.regions)
         name = (f"cfg4: SIAlphaModelEKFOptControlled sweep, {args.regions} regions x {args.eps} cost weights x "
+                f"({args.t_hist}+{args.horizon}) days")
+    elif args.workload == "newcase":
+        w = synth.make_newcase_sweep(args.regions, args.eps, args.t_hist, args.horizon)
+        name = (f"newcase: NewCaseEKFEstimatorWithOptimalNPI sweep, {args.regions} regions x {args.eps} cost weights x "
                 f"({args.t_hist}+{args.horizon}) days")
     elif args.workload == "cfg3":
         w = synth.make_cfg3(args.regions, args.t_hist, region_offset=rank * args.regions)
@@ -231,6 +235,9 @@ def main():
         # output of its own -- its algorithmic bytes are the P_MINUS it must read (m*m doubles)
         alg = {"ekf_fwd": BYTES_FWD[m] if full else 112, "eks_pinv": 8 * m * m,
                "eks_bwd": BYTES_BWD[m] if full else 8 * (m + 12)}
+        if w.model.startswith("NewCase"):     # no u_opt_smooth output, no separate pinv stage (mrdivide inline)
+            alg["eks_bwd"] = 8 * (m + m * m) if full else 8 * m
+            alg["eks_pinv"] = 0
         ms = {"ekf_fwd": ms_fwd, "eks_pinv": ms_pinv, "eks_bwd": ms_bwd}
         dom = max(ms, key=ms.get)
         dom_bytes = alg[dom] * steps_per_pass

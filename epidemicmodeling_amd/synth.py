@@ -429,6 +429,23 @@ def make_row4(n_regions: int = 4, T: int = 200, predict_ahead: int = 90, codegen
                     Ps_final=np.full((36, B), np.nan), Q=Q, meta={"workload": "row4", "regions": n_regions})
 
 
+def make_newcase_sweep(n_regions: int = 300, n_eps: int = 250, T_hist: int = 400, horizon: int = 120,
+                       codegen: bool = False) -> Workload:
+    """BASELINE config "NewCaseEKFEstimatorWithOptimalNPI: 300 regions x 250 NPI-cost weights x 120-day horizon":
+    the row-4 parameterisation of every region replicated over the cost-weight grid (chain c = r * n_eps + e shares
+    region r's series), observations missing and controls free over the horizon."""
+    base = make_row4(n_regions, T_hist + horizon, horizon, codegen=codegen)
+    x = base.x.copy(); x[T_hist:] = np.nan
+    rr = np.repeat(np.arange(n_regions), n_eps)
+    prm = np.ascontiguousarray(base.prm[:, rr])
+    prm[L.PRM_EPSILON] = np.tile(epsilon_grid(n_eps), n_regions)
+    pick = lambda a: np.ascontiguousarray(a[:, rr])
+    return Workload(model=base.model, T=base.T, n_npi=NUM_NPI, x=x, u=base.u, R_series=None, R_scalar=pick(base.R_scalar[None])[0],
+                    x_series=rr.astype(np.int32), u_series=rr.astype(np.int32), prm=prm, s_init=pick(base.s_init),
+                    Ps_init=pick(base.Ps_init), s_final=pick(base.s_final), Ps_final=pick(base.Ps_final), Q=pick(base.Q),
+                    meta={"workload": "newcase", "regions": n_regions, "n_eps": n_eps, "T_hist": T_hist, "horizon": horizon})
+
+
 def as_backward(w: Workload) -> Workload:
     """The same inputs routed to the time-flipped wrapper (SIAlphaModelBackwardEKF[OptControlled]).
     The wrapper starts the flipped filter from (s_final, Ps_final), so those must be finite: the
