@@ -456,3 +456,40 @@ def test_nnls_affine_fit_loop_semantics():
             assert f["b"] == 0.0
     f0 = olib.nnls_affine_fit(Xs, ys, max_iters=0)
     assert f0["b"] == 0.0 and f0["iters"] == 0
+
+
+# ---------------------------------------------------------------- golden vectors of the stages around the filter
+def _aux(name):
+    import os
+    return np.load(os.path.join(H.ROOT, "tests", "golden", name + ".npz"))
+
+
+def test_oracle_reproduces_aux_golden_vectors():
+    """Committed fixtures (tests/golden/make_golden_aux.py) pin the oracle's Rt_ExpFitEKF, preprocessing, NNLS, plans and
+    Pareto filter: integer / selection outputs bit for bit; floating-point outputs bit for bit too on this toolchain,
+    with a 1e-12 allowance for libm's exp/tanh in Rt_ExpFitEKF should the host's libm differ."""
+    for order in (1, 2):
+        g = _aux(f"aux_rt_order{order}")
+        ob = olib.rt_expfit_batch(g["in_x"], g["in_rp"], int(g["in_L"]), order)
+        for k, v in ob.items():
+            assert H.rel_err(v, g["out_" + k]) <= 1e-12, (order, k)
+    g = _aux("aux_preprocess")
+    for r in range(g["in_cases"].shape[1]):
+        o = olib.preprocess_region(g["in_cases"][:, r], g["in_deaths"][:, r], g["in_population"][r])
+        for k in ("new_refined", "new_smoothed", "zero_lag", "x_new", "x_total", "R_v", "fatality"):
+            assert np.array_equal(o[k], g["out_" + k][:, r]), (r, k)
+        assert o["I0"] == g["out_I0"][r]
+        assert np.array_equal(olib.npi_fill(np.ascontiguousarray(g["in_ip"][:, :, r])), g["out_ip_filled"][:, :, r])
+    g = _aux("aux_nnls")
+    for s in range(g["in_X"].shape[2]):
+        f = olib.nnls_affine_fit(np.ascontiguousarray(g["in_X"][:, :, s]), np.ascontiguousarray(g["in_y"][:, s]))
+        assert np.array_equal(f["a"], g["out_a"][:, s]) and f["b"] == g["out_b"][s] and f["iters"] == g["out_iters"][s]
+    g = _aux("aux_scenarios")
+    P = g["out_plans"]
+    for j in range(P.shape[0]):
+        for r in range(P.shape[1]):
+            assert np.array_equal(olib.random_npi_plan(int(g["in_seed"]), r, j, int(g["in_n_scen"]), int(g["in_K"]),
+                                                       np.zeros(12), synth.IP_MAXES), P[j, r])
+    for r in range(g["in_J0"].shape[0]):
+        on, io = olib.pareto_front(g["in_J0"][r], g["in_J1"][r])
+        assert np.array_equal(on, g["out_on_front"][r]) and io == g["out_i_opt"][r]
