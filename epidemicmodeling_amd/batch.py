@@ -345,7 +345,8 @@ def seirp_sim(par, init, dt, K, sat=None, integrator="euler", device="cuda:0"):
     """Batched SEIRP / SEIRPSaturatedResource.  par [K or 1, 7, B], init [5, B], sat [6, B] or None.
     Returns torch tensor [K, 5, B] (s,e,i,r,p rows; row 0 is the initial condition, SEIRP.m:20-24)."""
     dev = torch.device(device)
-    t = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev)
+    t = lambda a: None if a is None else (a.contiguous() if isinstance(a, torch.Tensor) else
+                                          torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev))
     par, init, sat = t(par), t(init), t(sat)
     B = init.shape[1]
     out = torch.empty((K, 5, B), dtype=torch.float64, device=dev)
