@@ -90,6 +90,14 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
 #endif
 #ifndef EPI_BWD_LB
 #define EPI_BWD_LB kWave
+// measured on the headline sweep (profiles/ab_phase.py 4, median of 15): no prefetch 9.4 ms; small group one step ahead
+// 8.0 ms; + P_PLUS or X 8.2-8.8 ms (they push the kernel into scratch or cost more moves than the latency they hide)
+#ifndef EPI_BWD_PREFETCH
+#define EPI_BWD_PREFETCH 1
+#endif
+#ifndef EPI_BWD_RECOMPUTE
+#define EPI_BWD_RECOMPUTE 1
+#endif
 #endif
 constexpr int kPipeLanes = 40;   // lanes per workgroup of the LP = 1 forward variant
 // where the forward kernel keeps the model constants (see ekf_fwd_sym)
@@ -401,14 +409,18 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     // (they are the recursion state anyway) and stored at the top of the NEXT iteration, right after that
     // iteration's loads have been issued.
     BwdIn<M> cur;
-    auto fetch = [&](int k, BwdIn<M> &d) {
+    // the inputs of a step in two groups: the small ones that the step needs first (state, controls, rank word) and the
+    // two packed 6 x 6 (P_PLUS, X).  EPI_BWD_PREFETCH selects what is requested one step ahead (bit 0: the small group,
+    // bit 1: P_PLUS, bit 2: X); whatever is not prefetched is loaded at the top of its own step.
+    auto fetch_small = [&](int k, BwdIn<M> &d) {
         const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
         load_vec<M>(a.S_PLUS, t, B, c, d.Sp);
-        load_sym<M>(a.P_PLUS, t, B, c, d.Pp);
         load_u(a, t, su, d.u);
         d.rk = ldg_i(a.rankbuf + (size_t)t1 * B, (unsigned)c * 4u);
-        load_packed<M>(a.X, t1, B, c, d.X);       // unused garbage where the :211 guard fired (rk < 0)
     };
+    auto fetch_pp = [&](int k, BwdIn<M> &d) { load_sym<M>(a.P_PLUS, tpos<FLIP>(k, T), B, c, d.Pp); };
+    // (unused garbage where the :211 guard fired, rk < 0)
+    auto fetch_x = [&](int k, BwdIn<M> &d) { load_packed<M>(a.X, tpos<FLIP>(k + 1, T), B, c, d.X); };
     int t_pend = -1, rank_pend = -1;
     double u_pend[kNpi];
 #pragma unroll
@@ -421,21 +433,30 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         if (a.u_opt_smooth) store_u(a.u_opt_smooth, a, t_pend, c, u_pend);
     };
 
+    // double buffering: the inputs of step k-1 are requested at the top of step k (ahead of the stores of step k+1's
+    // results) and consumed one iteration later, so that a lone wave does not sit through a full memory round trip
+    // at the start of every step
+    constexpr int PF = (M == 6) ? EPI_BWD_PREFETCH : 0;   // the 3-state kernel would drop from two waves per SIMD to one
+    BwdIn<M> nxt;
     auto step = [&](int k) {
         const int t = tpos<FLIP>(k, T);
-        fetch(k, cur);
+        if (PF & 1) { if (k > 0) fetch_small(k - 1, nxt); } else fetch_small(k, cur);
+        if (PF & 2) { if (k > 0) fetch_pp(k - 1, nxt); } else fetch_pp(k, cur);
+        if (PF & 4) { if (k > 0) fetch_x(k - 1, nxt); } else fetch_x(k, cur);
         flush();
         // s(k+1|k) and P(k+1|k) are NOT read back: they are recomputed from the stored s(k|k), P(k|k), u(:,k) with
         // the forward kernel's own functions (:155-164) -- bit-identical, and 27 fewer loads per step for a kernel
         // that is bound by the number of memory operations a CU can issue
         double A[M * M], Sm1[M];
         state_jacobians<M, FLIP>(p, cur.u, cur.Sp, A);         // :206 (and :157 of the forward pass)
-        {
+        if (EPI_BWD_RECOMPUTE) {
             double u_app[kNpi];
 #pragma unroll
             for (int q = 0; q < kNpi; q++) u_app[q] = cur.u[q];
             nlin_state_update<M, FLIP>(p, a.mf, u_app, cur.Sp, Sm1);
             state_hard_margins<M>(p, Sm1);
+        } else {
+            load_vec<M>(a.S_MINUS, tpos<FLIP>(k + 1, T), B, c, Sm1);
         }
         double J[M * M];
         int rank = -1;
@@ -493,7 +514,8 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             // (see ekf_fwd_sym)
             // (P(k+1|k) is formed only now, after X has been consumed by J: the two are never live together)
             double Dsym[NS];
-            predict_cov_sym<M>(A, cur.Pp, Qd, Dsym);
+            if (EPI_BWD_RECOMPUTE) predict_cov_sym<M>(A, cur.Pp, Qd, Dsym);
+            else load_sym<M>(a.P_MINUS, tpos<FLIP>(k + 1, T), B, c, Dsym);
 #pragma unroll
             for (int e = 0; e < NS; e++) Dsym[e] = Dsym[e] - Ps[e];
             double F[M * M];
@@ -529,7 +551,25 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         }
         t_pend = t;
         rank_pend = rank;
+        if (PF & 1) {
+#pragma unroll
+            for (int i = 0; i < M; i++) cur.Sp[i] = nxt.Sp[i];
+#pragma unroll
+            for (int q = 0; q < kNpi; q++) cur.u[q] = nxt.u[q];
+            cur.rk = nxt.rk;
+        }
+        if (PF & 2) {
+#pragma unroll
+            for (int e = 0; e < NS; e++) cur.Pp[e] = nxt.Pp[e];
+        }
+        if (PF & 4) {
+#pragma unroll
+            for (int e = 0; e < M * M; e++) cur.X[e] = nxt.X[e];
+        }
     };
+    if ((PF & 1) && T >= 2) fetch_small(T - 2, cur);
+    if ((PF & 2) && T >= 2) fetch_pp(T - 2, cur);
+    if ((PF & 4) && T >= 2) fetch_x(T - 2, cur);
     for (int k = T - 2; k >= 0; k--) step(k);
     flush();
     if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
