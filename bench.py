@@ -39,8 +39,8 @@ BYTES_BWD = {3: 8 * (3 + 9 + 12), 6: 8 * (6 + 36 + 12)}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--regions", type=int, default=300)
     ap.add_argument("--eps", type=int, default=250)
     ap.add_argument("--t-hist", type=int, default=400)
