@@ -53,6 +53,8 @@ def parse():
                          "stream, one launch per kernel and pass, so that rocprofv3's per-kernel averages and the HIP-event "
                          "averages of this script describe the same launches; -1 = whole one-wave-per-SIMD rounds + a tail "
                          "chunk whose kernels run beside the main chunk's eks_pinv grid (about 1 ms per pass faster)")
+    ap.add_argument("--lane-block", type=int, default=8,
+                    help="output layout (epi_batch_desc.lane_block): 8 = chain-blocked (default), 0 = classic [T][rows][B]")
     ap.add_argument("--no-score", action="store_true",
                     help="skip the scenario-scoring tail (SIalpha_Controlled + NPICost on the horizon) after each pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,7 +153,7 @@ def main():
     m = w.m
     outputs = None if args.outputs == "all" else ["u_opt_smooth", "S_SMOOTH"]
     dw = batch.DeviceWorkload(w, dev)
-    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks)
+    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks, lane_block=args.lane_block)
     steps_per_pass = w.B * w.T
     t_hist_idx = w.meta.get("T_hist", w.T) - 1
 
@@ -170,12 +172,12 @@ def main():
         sp[batch.SIM_A:batch.SIM_A + n] = prm[L_.PRM_A:L_.PRM_A + n]
         sp[batch.SIM_U_MAX:batch.SIM_U_MAX + n] = prm[L_.PRM_U_MAX:L_.PRM_U_MAX + n]
         sp[batch.SIM_W:batch.SIM_W + n] = 1.0                       # npi_weights = ones (testPrescribeXPRIZE02.m:56)
-        S = runner.out["S_SMOOTH"]
+        S = runner.unblocked("S_SMOOTH")
         th = t_hist_idx + 1
         # historic prefixes are inputs of the scoring step (in the reference they come from the 3-state run of the
         # region); computed once, outside the timed region
         score_state["J0p"] = (S[:th, 0] * S[:th, 1] * S[:th, 2]).sum(dim=0)
-        score_state["J1p"] = runner.out["u_opt_smooth"][:th].sum(dim=(0, 1))
+        score_state["J1p"] = runner.unblocked("u_opt_smooth")[:th].sum(dim=(0, 1))
         score_state["sp"] = sp
 
     def one_step(events=None):
@@ -187,15 +189,15 @@ def main():
             runner.run(phase=4); e3.record()
         if score and score_state:
             sp = score_state["sp"]
-            sp[0:3].copy_(runner.out["S_SMOOTH"][t_hist_idx, 0:3])
-            sc = batch.score_sweep(runner.out["u_opt_smooth"], t_hist_idx + 1, sp, score_state["J0p"], score_state["J1p"])
+            sp[0:3].copy_(runner.unblocked_at("S_SMOOTH", t_hist_idx)[0:3])
+            sc = batch.score_sweep(runner.out["u_opt_smooth"], t_hist_idx + 1, sp, score_state["J0p"], score_state["J1p"], B=w.B)
             # Pareto-front filter + optimum per region (TrainPredictPrescribeNPI.m:624-633), still on the device
             score_state["front"] = batch.pareto_front(sc["J0"], sc["J1"], w.Sx)
             if world > 1:
                 batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
         elif world > 1:
             # no scoring: gather the per-chain smoothed state at the last observed day to rank 0
-            batch.gather_to_root(runner.out["S_SMOOTH"][t_hist_idx].contiguous())
+            batch.gather_to_root(runner.unblocked_at("S_SMOOTH", t_hist_idx).contiguous())
 
     one_step()
     torch.cuda.synchronize(dev)
@@ -250,6 +252,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "chunks": args.chunks,
+                       "lane_block": args.lane_block,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
                        "scoring_tail": bool(score),

@@ -34,7 +34,8 @@ class EpiError(RuntimeError):
 class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "model", "B", "T", "Sx", "Su", "n_npi", "L", "order",
                                           "obs_type", "r_mode", "q_mode")] + [
-        ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("chunks", C.c_int32)]
+        ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("chunks", C.c_int32),
+        ("lane_block", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -49,7 +50,8 @@ class Outputs(C.Structure):
 
 
 class SimDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("abi_version", "B", "K", "Su", "n_npi", "noise", "with_cost", "prefix_days")]
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "B", "K", "Su", "n_npi", "noise", "with_cost", "prefix_days",
+                                          "u_block")]
 
 
 class McDesc(C.Structure):
@@ -180,5 +182,5 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask,
     else:
         d.obs_type = int(obs_type)
     d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), int(q_mode), int(out_mask), 0
-    d.path_hint, d.chunks = 0, 0
+    d.path_hint, d.chunks, d.lane_block = 0, 0, 0
     return d

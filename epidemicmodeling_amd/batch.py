@@ -61,11 +61,13 @@ class DeviceWorkload:
 class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
-    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True):
+    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True, lane_block=0):
         """chunks > 1: a full run() is split into that many chain chunks on helper streams (overlaps the
         (chain, step)-parallel pinv grid with the sequential kernels of the other chunks).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
-        run() enqueues only the variant that will actually execute."""
+        run() enqueues only the variant that will actually execute.  lane_block: 0 = classic [T][rows][B] outputs;
+        8 = chain-blocked outputs (epi_batch_desc.lane_block): `out` then holds the raw blocked tensors
+        [T, nblk, rows, blk] ([T, nblk*blk] for one-row arrays) and unblocked() returns [T, rows, B] copies."""
         self.dw = dw
         names = list(OUT_NAMES) if outputs is None else list(outputs)
         if dw.model.startswith("NewCase") and "u_opt_smooth" in names:
@@ -74,6 +76,9 @@ class EkfRunner:
         self.mask = out_mask_of(names)
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
                                    dw.r_mode, self.mask, dw.q_mode)
+        self.blk = dw.B if (lane_block <= 0 or lane_block >= dw.B) else int(lane_block)
+        self.nblk = (dw.B + self.blk - 1) // self.blk
+        self.desc.lane_block = 0 if self.blk == dw.B else self.blk
         self.err = C.create_string_buffer(256)
         h = _lib.lib()
         _lib.check(h.epi_ekf_validate(C.byref(self.desc), self.err), self.err)
@@ -81,9 +86,12 @@ class EkfRunner:
         self.out = {}
         for n in names:
             rows = L.out_rows(n, dw.m, dw.n_npi)
-            shape = (dw.T, dw.B) if rows == 0 else (dw.T, rows, dw.B)
+            if self.blk == dw.B:
+                shape = (dw.T, dw.B) if rows == 0 else (dw.T, rows, dw.B)
+            else:
+                shape = (dw.T, self.nblk * self.blk) if rows == 0 else (dw.T, self.nblk, rows, self.blk)
             self.out[n] = torch.empty(shape, dtype=torch.float64, device=dev)
-        self.pinv_rank = torch.empty((dw.T, dw.B), dtype=torch.int32, device=dev) if extras else None
+        self.pinv_rank = torch.empty((dw.T, self.nblk * self.blk), dtype=torch.int32, device=dev) if extras else None
         self.status = torch.zeros((dw.B,), dtype=torch.int32, device=dev) if extras else None
         self.ws_bytes = int(h.epi_ekf_workspace_bytes(C.byref(self.desc)))
         self.ws = torch.empty((max(self.ws_bytes, 8) + 7) // 8, dtype=torch.float64, device=dev)
@@ -112,19 +120,39 @@ class EkfRunner:
         _lib.check(rc, self.err)
         return self.out
 
+    def unblocked(self, name):
+        """[T, rows, B] ([T, B]) tensor of output `name` whatever the layout run() wrote it in."""
+        t = self.pinv_rank if name == "pinv_rank" else self.out[name]
+        if self.blk == self.dw.B:
+            return t
+        if t.dim() == 2:
+            return t[:, :self.dw.B]
+        T, nb, rows, blk = t.shape
+        return t.permute(0, 2, 1, 3).reshape(T, rows, nb * blk)[:, :, :self.dw.B]
+
+    def unblocked_at(self, name, t):
+        """[rows, B] slice of output `name` at time index t (no copy of the whole array)."""
+        x = self.out[name][t]
+        if self.blk == self.dw.B:
+            return x
+        if x.dim() == 1:
+            return x[:self.dw.B]
+        nb, rows, blk = x.shape
+        return x.permute(1, 0, 2).reshape(rows, nb * blk)[:, :self.dw.B]
+
     def output_bytes(self) -> int:
         return sum(t.numel() * 8 for t in self.out.values())
 
 
-def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True):
-    """Convenience: upload `w`, run once, return dict name -> numpy array (+ pinv_rank/status)."""
+def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True, lane_block=0):
+    """Convenience: upload `w`, run once, return dict name -> numpy array [T, rows, B] (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
-    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck)
+    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck, lane_block=lane_block)
     r.run()
     torch.cuda.synchronize(dw.device)
-    res = {n: t.cpu().numpy() for n, t in r.out.items()}
+    res = {n: r.unblocked(n).cpu().numpy() for n in r.out}
     if extras:
-        res["pinv_rank"] = r.pinv_rank.cpu().numpy()
+        res["pinv_rank"] = r.unblocked("pinv_rank").cpu().numpy()
         res["status"] = r.status.cpu().numpy()
     return res
 
@@ -359,22 +387,29 @@ def seirp_sim(par, init, dt, K, sat=None, integrator="euler", device="cuda:0"):
     return out
 
 
-def score_sweep(u_opt_smooth, t_hist, sp, J0_prefix, J1_prefix, store=False):
+def score_sweep(u_opt_smooth, t_hist, sp, J0_prefix, J1_prefix, store=False, B=None):
     """Scenario scoring tail of the Pareto sweep (Tools/TrainPredictPrescribeNPI.m:481-493) on the device.
 
-    u_opt_smooth : torch [T, n_npi, B] (the smoother's output, left in HBM); its last T - t_hist days drive
+    u_opt_smooth : torch [T, n_npi, B] (the smoother's output, left in HBM) or, chain-blocked, [T, nblk, n_npi, blk]
+                   (then pass the number of chains B); its last T - t_hist days drive
                    SIalpha_Controlled from the end-of-history state given in `sp` (SIM_* rows, [48, B]);
     J0_prefix/J1_prefix : [B] sequential sums over the t_hist historic days (newcases; weights.*inputs).
     Returns dict with J0, J1 [B] (NPICost over the whole span) and, if store, the simulated s, i, alpha [H, B]."""
     dev = u_opt_smooth.device
-    T, n_npi, B = u_opt_smooth.shape
+    if u_opt_smooth.dim() == 4:
+        T, _, n_npi, u_block = u_opt_smooth.shape
+        if B is None:
+            raise ValueError("blocked u_opt_smooth needs the number of chains B")
+    else:
+        T, n_npi, B = u_opt_smooth.shape
+        u_block = 0
     H = T - t_hist
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(dev) if not isinstance(a, torch.Tensor) else a
     sp, J0p, J1p = t(sp), t(J0_prefix), t(J1_prefix)
     u_h = u_opt_smooth[t_hist:]                 # contiguous view: [H, n_npi, B]
     d = _lib.SimDesc()
     d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, B, H, B, n_npi
-    d.noise, d.with_cost, d.prefix_days = 0, 1, int(t_hist)
+    d.noise, d.with_cost, d.prefix_days, d.u_block = 0, 1, int(t_hist), int(u_block)
     out = {"J0": torch.empty((B,), dtype=torch.float64, device=dev), "J1": torch.empty((B,), dtype=torch.float64, device=dev)}
     if store:
         for n in ("s", "i", "alpha"):

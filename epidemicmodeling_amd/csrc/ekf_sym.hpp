@@ -31,21 +31,21 @@ template <int M> constexpr bool a_nz(int i, int k)
 }
 
 template <int M>
-EPI_DEV void store_sym(double *__restrict__ dst, int t, int B, int c, const double (&P)[nsym<M>()])
+EPI_DEV void store_sym(double *__restrict__ dst, int t, const Lay &l, const double (&P)[nsym<M>()])
 {
     if (!dst) return;
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
-    const rsrc_t r = mk_rsrc(dst + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(dst, t, M * M, l, voff, rowb);
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
         for (int i = 0; i < M; i++) bst(r, voff, (unsigned)IXM(i, j) * rowb, P[sidx(i, j)]);
 }
 template <int M>
-EPI_DEV void load_sym(const double *__restrict__ src, int t, int B, int c, double (&P)[nsym<M>()])
+EPI_DEV void load_sym(const double *__restrict__ src, int t, const Lay &l, double (&P)[nsym<M>()])
 {
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
-    const rsrc_t r = mk_rsrc(src + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(src, t, M * M, l, voff, rowb);
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
@@ -90,13 +90,19 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
 #endif
 #ifndef EPI_BWD_LB
 #define EPI_BWD_LB kWave
-// measured on the headline sweep (profiles/ab_phase.py 4, median of 15): no prefetch 9.4 ms; small group one step ahead
-// 8.0 ms; + P_PLUS or X 8.2-8.8 ms (they push the kernel into scratch or cost more moves than the latency they hide)
+// Two knobs of the packed smoother, settled by A/B runs on the headline sweep (profiles/ab_phase.py 4, medians):
+//   EPI_BWD_PREFETCH  what is requested one step ahead (bit 0: state, controls, rank word; bit 1: P_PLUS; bit 2: X)
+//   EPI_BWD_RECOMPUTE 1: s(k+1|k), P(k+1|k) are recomputed from the stored s(k|k), P(k|k), u with the forward kernel's
+//                     own functions (bit-identical, 27 fewer loads per step, 10 GB less traffic per pass) -- but the
+//                     kernel then needs all 512 registers, and with the prefetch and the blocked-layout addressing on
+//                     top it spills (56 B of scratch per lane: 12.5 ms);  0: they are read back at their point of use.
+//   chain-blocked outputs, blk = 8:  recompute 0 / prefetch 1: 8.0 ms (372 VGPRs)   0 / 5: 8.1   0 / 0: 8.4   1 / 0: 9.5
+//   classic [T][rows][B]:            0 / 1: 8.6   0 / 0: 9.1   1 / 0: 9.6
 #ifndef EPI_BWD_PREFETCH
 #define EPI_BWD_PREFETCH 1
 #endif
 #ifndef EPI_BWD_RECOMPUTE
-#define EPI_BWD_RECOMPUTE 1
+#define EPI_BWD_RECOMPUTE 0
 #endif
 #endif
 constexpr int kPipeLanes = 40;   // lanes per workgroup of the LP = 1 forward variant
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
 
     constexpr int stride = LP ? kPipeLanes : kWave;   // compile-time: LDS offsets stay immediates
     typename PrmSelect<LP>::type p;
@@ -230,8 +237,8 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
             load_u(a, tn, su, u_nxt);
         }
 
-        store_vec<M>(a.S_MINUS, t, B, c, sk_minus);
-        store_sym<M>(a.P_MINUS, t, B, c, Pm);
+        store_vec<M>(a.S_MINUS, t, lay, sk_minus);
+        store_sym<M>(a.P_MINUS, t, lay, Pm);
 
         double C[M];
         obs_jacobian<M>(a.mf, sk_minus, C);                 // C(4:6) == 0 for m = 6
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
 #pragma unroll
         for (int q = 0; q < kNpi; q++) u_app[q] = u_in[q];
         nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
-        store_u(a.u_opt, a, t, c, u_app);
+        store_u(a.u_opt, a, t, lay, u_app);
         {
             double A[M * M];
             state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
@@ -313,10 +320,10 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         }
         state_hard_margins<M>(p, sk_minus);
 
-        store_vec<M>(a.S_PLUS, t, B, c, sk_plus);
-        store_sym<M>(a.P_PLUS, t, B, c, Pp);
-        store_vec<M>(a.K_GAIN, t, B, c, K);
-        if (a.innovations) stg(a.innovations + (size_t)t * B, voff, innov);
+        store_vec<M>(a.S_PLUS, t, lay, sk_plus);
+        store_sym<M>(a.P_PLUS, t, lay, Pp);
+        store_vec<M>(a.K_GAIN, t, lay, K);
+        if (a.innovations) a.innovations[lay_scalar(t, lay)] = innov;
 
         // innovation monitor (identical to ekf_fwd)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         winCov[head * stride] = cc;
         winCovN[head * stride] = ccn;
         const double sumN = ring_sum(winCovN, head, L, ccn, stride);
-        if (a.rho) stg(a.rho + (size_t)t * B, voff, sumN / (double)cnt);
+        if (a.rho) a.rho[lay_scalar(t, lay)] = sumN / (double)cnt;
         if (fixed_R) {
             if (beta != 1.0 && valid && k < T - 1) {
                 const double sumC = ring_sum(winCov, head, L, cc, stride);
@@ -360,6 +367,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     if (lane >= a.lw || c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
     LitePrm<VecLds> p;
     load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
     p.v.base = vlds + lane;
@@ -379,13 +387,13 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     // is symmetric (values and NaN pattern), so P_SMOOTH(:,:,T) is symmetric and stays packed.
     double Ss[M], Ps[NS];
     const int tT = tpos<FLIP>(T - 1, T);
-    load_vec<M>(a.S_PLUS, tT, B, c, Ss);
+    load_vec<M>(a.S_PLUS, tT, lay, Ss);
 #pragma unroll
     for (int i = 0; i < M; i++) {
         const double f = a.s_final[(size_t)i * B + c];
         if (!is_nan(f)) Ss[i] = f;
     }
-    load_sym<M>(a.P_PLUS, tT, B, c, Ps);
+    load_sym<M>(a.P_PLUS, tT, lay, Ps);
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
@@ -393,15 +401,15 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             const double f = a.Ps_final[(size_t)IXM(i, j) * B + c];
             if (!is_nan(f)) Ps[sidx(i, j)] = f;
         }
-    store_vec<M>(a.S_SMOOTH, tT, B, c, Ss);
-    store_sym<M>(a.P_SMOOTH, tT, B, c, Ps);
+    store_vec<M>(a.S_SMOOTH, tT, lay, Ss);
+    store_sym<M>(a.P_SMOOTH, tT, lay, Ps);
     if (a.u_opt_smooth) {
         double z[kNpi];
 #pragma unroll
         for (int k = 0; k < kNpi; k++) z[k] = 0.0;
-        store_u(a.u_opt_smooth, a, tT, c, z);
+        store_u(a.u_opt_smooth, a, tT, lay, z);
     }
-    if (a.pinv_rank) a.pinv_rank[(size_t)tT * B + c] = -1;
+    if (a.pinv_rank) a.pinv_rank[lay_scalar(tT, lay)] = -1;
 
     int st_guard = 0, st_cap = 0, min_rank = M;
     // Software pipeline.  Vector-memory operations retire in issue order, so loads issued after a step's
@@ -414,23 +422,23 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     // bit 1: P_PLUS, bit 2: X); whatever is not prefetched is loaded at the top of its own step.
     auto fetch_small = [&](int k, BwdIn<M> &d) {
         const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
-        load_vec<M>(a.S_PLUS, t, B, c, d.Sp);
+        load_vec<M>(a.S_PLUS, t, lay, d.Sp);
         load_u(a, t, su, d.u);
-        d.rk = ldg_i(a.rankbuf + (size_t)t1 * B, (unsigned)c * 4u);
+        d.rk = a.rankbuf[lay_scalar(t1, lay)];
     };
-    auto fetch_pp = [&](int k, BwdIn<M> &d) { load_sym<M>(a.P_PLUS, tpos<FLIP>(k, T), B, c, d.Pp); };
+    auto fetch_pp = [&](int k, BwdIn<M> &d) { load_sym<M>(a.P_PLUS, tpos<FLIP>(k, T), lay, d.Pp); };
     // (unused garbage where the :211 guard fired, rk < 0)
-    auto fetch_x = [&](int k, BwdIn<M> &d) { load_packed<M>(a.X, tpos<FLIP>(k + 1, T), B, c, d.X); };
+    auto fetch_x = [&](int k, BwdIn<M> &d) { load_packed<M>(a.X, tpos<FLIP>(k + 1, T), lay, d.X); };
     int t_pend = -1, rank_pend = -1;
     double u_pend[kNpi];
 #pragma unroll
     for (int q = 0; q < kNpi; q++) u_pend[q] = 0.0;
     auto flush = [&]() {          // store the previous step's results (Ss, Ps still hold them)
         if (t_pend < 0) return;
-        if (a.pinv_rank) stg_i(a.pinv_rank + (size_t)t_pend * B, (unsigned)c * 4u, rank_pend);
-        store_vec<M>(a.S_SMOOTH, t_pend, B, c, Ss);
-        store_sym<M>(a.P_SMOOTH, t_pend, B, c, Ps);
-        if (a.u_opt_smooth) store_u(a.u_opt_smooth, a, t_pend, c, u_pend);
+        if (a.pinv_rank) a.pinv_rank[lay_scalar(t_pend, lay)] = rank_pend;
+        store_vec<M>(a.S_SMOOTH, t_pend, lay, Ss);
+        store_sym<M>(a.P_SMOOTH, t_pend, lay, Ps);
+        if (a.u_opt_smooth) store_u(a.u_opt_smooth, a, t_pend, lay, u_pend);
     };
 
     // double buffering: the inputs of step k-1 are requested at the top of step k (ahead of the stores of step k+1's
@@ -444,9 +452,8 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         if (PF & 2) { if (k > 0) fetch_pp(k - 1, nxt); } else fetch_pp(k, cur);
         if (PF & 4) { if (k > 0) fetch_x(k - 1, nxt); } else fetch_x(k, cur);
         flush();
-        // s(k+1|k) and P(k+1|k) are NOT read back: they are recomputed from the stored s(k|k), P(k|k), u(:,k) with
-        // the forward kernel's own functions (:155-164) -- bit-identical, and 27 fewer loads per step for a kernel
-        // that is bound by the number of memory operations a CU can issue
+        // s(k+1|k) and P(k+1|k): read back at their point of use, or (EPI_BWD_RECOMPUTE) recomputed from the stored
+        // s(k|k), P(k|k), u(:,k) with the forward kernel's own functions (:155-164) -- bit-identical either way
         double A[M * M], Sm1[M];
         state_jacobians<M, FLIP>(p, cur.u, cur.Sp, A);         // :206 (and :157 of the forward pass)
         if (EPI_BWD_RECOMPUTE) {
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             nlin_state_update<M, FLIP>(p, a.mf, u_app, cur.Sp, Sm1);
             state_hard_margins<M>(p, Sm1);
         } else {
-            load_vec<M>(a.S_MINUS, tpos<FLIP>(k + 1, T), B, c, Sm1);
+            load_vec<M>(a.S_MINUS, tpos<FLIP>(k + 1, T), lay, Sm1);
         }
         double J[M * M];
         int rank = -1;
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             // (P(k+1|k) is formed only now, after X has been consumed by J: the two are never live together)
             double Dsym[NS];
             if (EPI_BWD_RECOMPUTE) predict_cov_sym<M>(A, cur.Pp, Qd, Dsym);
-            else load_sym<M>(a.P_MINUS, tpos<FLIP>(k + 1, T), B, c, Dsym);
+            else load_sym<M>(a.P_MINUS, tpos<FLIP>(k + 1, T), lay, Dsym);
 #pragma unroll
             for (int e = 0; e < NS; e++) Dsym[e] = Dsym[e] - Ps[e];
             double F[M * M];

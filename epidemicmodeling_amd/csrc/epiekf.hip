@@ -49,6 +49,8 @@ struct KArgs {
     int *dense_flag;
     // chain range [c0, c0 + cn) this launch covers (a call may be split into chunks on two streams)
     int c0, cn;
+    // chain-blocked layout of the output / workspace arrays (see Lay): lanes per block and blocks per time slice
+    int blk, nblk;
     // lanes used per 64-thread workgroup (<= 64).  When the batch needs more than one round of resident waves,
     // the host narrows the waves so that the rounds are equally full (launch_chain): the sequential kernels are
     // bound by HBM / per-CU memory throughput, which scales with active lanes, not by wave count.
@@ -87,47 +89,79 @@ EPI_DEV void stg(double *__restrict__ row, unsigned voff, double v) { *(double *
 EPI_DEV int ldg_i(const int32_t *__restrict__ row, unsigned voff4) { return *(const int32_t *)((const char *)row + voff4); }
 EPI_DEV void stg_i(int32_t *__restrict__ row, unsigned voff4, int v) { *(int32_t *)((char *)row + voff4) = v; }
 
+// Chain-blocked layout of the big per-(time, row, chain) arrays (the 11 outputs and the workspace).  Element
+// (t, row, c) of an array with `rows` rows lives at double index
+//     ((t * nblk + c / blk) * rows + row) * blk + c % blk,        nblk = ceil(B / blk).
+// blk = B (nblk = 1) is the classic [T][rows][B].  blk = 8 makes the rows of eight neighbouring chains one contiguous
+// rows * 64-byte block, so that the ~100 stores a wave issues per step fill whole DRAM pages instead of feeding ~100
+// concurrent row streams (profiles/layout_probe: 5.5 ms instead of 7.7-8.5 ms for the forward kernel's 32 GB of
+// stores).  Arrays with one row ([T][B]: innovations, rho, rank words) are simply [T][nblk * blk].
+struct Lay { unsigned blk, nblk, cb, cr, c, bp; };
+EPI_DEV Lay make_lay(const KArgs &a, int c)
+{
+    Lay l;
+    l.blk = (unsigned)a.blk; l.nblk = (unsigned)a.nblk; l.c = (unsigned)c;
+    l.cb = (unsigned)c / l.blk; l.cr = (unsigned)c - l.cb * l.blk; l.bp = l.blk * l.nblk;
+    return l;
+}
+// buffer descriptor of time slice t of an array with `rows` rows, this lane's byte offset in it, and the row pitch
+EPI_DEV rsrc_t lay_slice(const double *p, int t, unsigned rows, const Lay &l, unsigned &voff, unsigned &rowb)
+{
+    rowb = l.blk * 8u;
+    voff = (l.cb * rows * l.blk + l.cr) * 8u;
+    return mk_rsrc(p + (size_t)t * rows * l.bp, rows * l.bp * 8u);
+}
+// inputs that are per (time, row, chain) -- a time-varying Q_w -- keep the classic [T][rows][B]
+EPI_DEV Lay lay_classic(int B, int c)
+{
+    Lay l;
+    l.blk = (unsigned)B; l.nblk = 1u; l.c = (unsigned)c; l.cb = 0u; l.cr = (unsigned)c; l.bp = (unsigned)B;
+    return l;
+}
+EPI_DEV Lay make_lay_classic(const KArgs &a, int c) { return lay_classic(a.B, c); }
+EPI_DEV size_t lay_scalar(int t, const Lay &l) { return (size_t)t * l.bp + l.c; }   // index into a [T][nblk*blk] array
+
 template <int M>
-EPI_DEV void store_vec(double *__restrict__ dst, int t, int B, int c, const double (&v)[M])
+EPI_DEV void store_vec(double *__restrict__ dst, int t, const Lay &l, const double (&v)[M])
 {
     if (!dst) return;
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
-    const rsrc_t r = mk_rsrc(dst + (size_t)t * M * B, (unsigned)M * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(dst, t, M, l, voff, rowb);
 #pragma unroll
     for (int i = 0; i < M; i++) bst(r, voff, (unsigned)i * rowb, v[i]);
 }
 template <int M>
-EPI_DEV void store_mat(double *__restrict__ dst, int t, int B, int c, const double (&P)[M * M])
+EPI_DEV void store_mat(double *__restrict__ dst, int t, const Lay &l, const double (&P)[M * M])
 {
     if (!dst) return;
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
-    const rsrc_t r = mk_rsrc(dst + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(dst, t, M * M, l, voff, rowb);
 #pragma unroll
     for (int e = 0; e < M * M; e++) bst(r, voff, (unsigned)e * rowb, P[e]);
 }
 template <int M>
-EPI_DEV void load_vec(const double *__restrict__ src, int t, int B, int c, double (&v)[M])
+EPI_DEV void load_vec(const double *__restrict__ src, int t, const Lay &l, double (&v)[M])
 {
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
-    const rsrc_t r = mk_rsrc(src + (size_t)t * M * B, (unsigned)M * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(src, t, M, l, voff, rowb);
 #pragma unroll
     for (int i = 0; i < M; i++) v[i] = bld(r, voff, (unsigned)i * rowb);
 }
 template <int M>
-EPI_DEV void load_mat(const double *__restrict__ src, int t, int B, int c, double (&P)[M * M])
+EPI_DEV void load_mat(const double *__restrict__ src, int t, const Lay &l, double (&P)[M * M])
 {
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
-    const rsrc_t r = mk_rsrc(src + (size_t)t * (M * M) * B, (unsigned)(M * M) * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(src, t, M * M, l, voff, rowb);
 #pragma unroll
     for (int e = 0; e < M * M; e++) P[e] = bld(r, voff, (unsigned)e * rowb);
 }
-// full symmetric matrix from a packed upper-triangle array [T][M(M+1)/2][B]
+// full symmetric matrix from a packed upper-triangle array (M(M+1)/2 rows)
 template <int M>
-EPI_DEV void load_packed(const double *__restrict__ src, int t, int B, int c, double (&P)[M * M])
+EPI_DEV void load_packed(const double *__restrict__ src, int t, const Lay &l, double (&P)[M * M])
 {
     constexpr int NSX = M * (M + 1) / 2;
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)B * 8u;
-    const rsrc_t r = mk_rsrc(src + (size_t)t * NSX * B, (unsigned)NSX * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(src, t, NSX, l, voff, rowb);
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
@@ -137,6 +171,7 @@ EPI_DEV void load_packed(const double *__restrict__ src, int t, int B, int c, do
             P[IXM(j, i)] = v;
         }
 }
+// the control series stay [T][n_npi][Su] (inputs, shared by the chains of a region)
 EPI_DEV void load_u(const KArgs &a, int t, int su, double (&u)[kNpi])
 {
     const unsigned voff = (unsigned)su * 8u, rowb = (unsigned)a.Su * 8u;
@@ -144,11 +179,11 @@ EPI_DEV void load_u(const KArgs &a, int t, int su, double (&u)[kNpi])
 #pragma unroll
     for (int k = 0; k < kNpi; k++) u[k] = (k < a.n_npi) ? bld(r, voff, (unsigned)k * rowb) : 0.0;
 }
-EPI_DEV void store_u(double *__restrict__ dst, const KArgs &a, int t, int c, const double (&u)[kNpi])
+EPI_DEV void store_u(double *__restrict__ dst, const KArgs &a, int t, const Lay &l, const double (&u)[kNpi])
 {
     if (!dst) return;
-    const unsigned voff = (unsigned)c * 8u, rowb = (unsigned)a.B * 8u;
-    const rsrc_t r = mk_rsrc(dst + (size_t)t * a.n_npi * a.B, (unsigned)a.n_npi * rowb);
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(dst, t, (unsigned)a.n_npi, l, voff, rowb);
 #pragma unroll
     for (int k = 0; k < kNpi; k++)
         if (k < a.n_npi) bst(r, voff, (unsigned)k * rowb, u[k]);
@@ -168,6 +203,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
 
     ChainPrm p;
     load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero);
@@ -199,10 +235,10 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
         double u_in[kNpi];
         load_u(a, t, su, u_in);
         if (GENERIC && a.q_mode)   // Q(:,:,k): like R_v, Q_w is not time-flipped by the backward wrappers
-            load_mat<M>(a.Q, k, B, c, Q);
+            load_mat<M>(a.Q, k, make_lay_classic(a, c), Q);
 
-        store_vec<M>(a.S_MINUS, t, B, c, sk_minus);       // :100-101
-        store_mat<M>(a.P_MINUS, t, B, c, Pk_minus);
+        store_vec<M>(a.S_MINUS, t, lay, sk_minus);       // :100-101
+        store_mat<M>(a.P_MINUS, t, lay, Pk_minus);
 
         double C[M];
         obs_jacobian<M>(a.mf, sk_minus, C);               // :115
@@ -268,7 +304,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 #pragma unroll
         for (int q = 0; q < kNpi; q++) u_app[q] = u_in[q];
         nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
-        store_u(a.u_opt, a, t, c, u_app);
+        store_u(a.u_opt, a, t, lay, u_app);
         {
             double A[M * M], T1[M * M], T2[M * M];
             state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
@@ -280,10 +316,10 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
         if (GENERIC) symmetrize<M>(Pk_minus);              // :161
         state_hard_margins<M>(p, sk_minus);                // :164
 
-        store_vec<M>(a.S_PLUS, t, B, c, sk_plus);          // :167-169
-        store_mat<M>(a.P_PLUS, t, B, c, Pk_plus);
-        store_vec<M>(a.K_GAIN, t, B, c, K);
-        if (a.innovations) a.innovations[(size_t)t * B + c] = innov;
+        store_vec<M>(a.S_PLUS, t, lay, sk_plus);          // :167-169
+        store_mat<M>(a.P_PLUS, t, lay, Pk_plus);
+        store_vec<M>(a.K_GAIN, t, lay, K);
+        if (a.innovations) a.innovations[lay_scalar(t, lay)] = innov;
 
         // innovation monitor :172-185 -- windows are newest-first and summed front to back
         const int cnt = (k + 1 < L) ? (k + 1) : L;
@@ -296,7 +332,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
         winCov[head * kWave] = cc;
         winCovN[head * kWave] = ccn;
         const double sumN = ring_sum(winCovN, head, L, ccn);
-        if (a.rho) a.rho[(size_t)t * B + c] = sumN / (double)cnt;
+        if (a.rho) a.rho[lay_scalar(t, lay)] = sumN / (double)cnt;
         if (fixed_R) {
             const bool adapt = GENERIC ? (beta != 1.0 && valid && k < T - 1) : (beta != 1.0 && valid);
             if (adapt) {
@@ -327,12 +363,12 @@ __global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
     // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
     const int t1 = a.pinv_pos0 + (int)blockIdx.y;
     const int c = a.c0 + cl;
-    const unsigned voff = (unsigned)c * 8u;
+    const Lay lay = make_lay(a, c);
     double P[M * M];
     // P_MINUS is stored symmetrised (:161): read the upper triangle only and mirror it
     {
-        const unsigned rowb = (unsigned)B * 8u;
-        const rsrc_t r = mk_rsrc(a.P_MINUS + (size_t)t1 * (M * M) * B, (unsigned)(M * M) * rowb);
+        unsigned voff, rowb;
+        const rsrc_t r = lay_slice(a.P_MINUS, t1, M * M, lay, voff, rowb);
 #pragma unroll
         for (int j = 0; j < M; j++)
 #pragma unroll
@@ -347,24 +383,24 @@ __global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
     for (int j = 0; j < M; j++)
 #pragma unroll
         for (int i = 0; i <= j; i++) bad = bad || is_nonfinite(P[IXM(i, j)]);
-    int32_t *rrow = a.rankbuf + (size_t)t1 * B;
+    int32_t *rword = a.rankbuf + lay_scalar(t1, lay);
     if (bad) {
-        stg_i(rrow, (unsigned)c * 4u, -1);
+        *rword = -1;
         return;
     }
     double X[M * M];
     bool capped;
     const int rank = sym_pinv<M>(P, X, &capped);           // :215
-    {   // X is symmetric bit for bit: the workspace holds its packed upper triangle, [T][M(M+1)/2][B]
+    {   // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
         constexpr int NSX = M * (M + 1) / 2;
-        const unsigned rowb = (unsigned)B * 8u;
-        const rsrc_t r = mk_rsrc(a.X + (size_t)t1 * NSX * B, (unsigned)NSX * rowb);
+        unsigned voff, rowb;
+        const rsrc_t r = lay_slice(a.X, t1, NSX, lay, voff, rowb);
 #pragma unroll
         for (int j = 0; j < M; j++)
 #pragma unroll
             for (int i = 0; i <= j; i++) bst(r, voff, (unsigned)(i + j * (j + 1) / 2) * rowb, X[IXM(i, j)]);
     }
-    stg_i(rrow, (unsigned)c * 4u, rank | (capped ? 0x100 : 0));
+    *rword = rank | (capped ? 0x100 : 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -378,14 +414,15 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
     if ((int)threadIdx.x >= a.lw || c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
     ChainPrm p;
     load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero);
 
     // terminal conditions :189-202
     double Ss[M], Ps[M * M];
     const int tT = tpos<FLIP>(T - 1, T);
-    load_vec<M>(a.S_PLUS, tT, B, c, Ss);
-    load_mat<M>(a.P_PLUS, tT, B, c, Ps);
+    load_vec<M>(a.S_PLUS, tT, lay, Ss);
+    load_mat<M>(a.P_PLUS, tT, lay, Ps);
 #pragma unroll
     for (int i = 0; i < M; i++) {
         double f = a.s_final[(size_t)i * B + c];
@@ -416,24 +453,24 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
                     if (rows[i] && cols[j]) Ps[IXM(i, j)] = Pf[IXM(i, j)];
         }
     }
-    store_vec<M>(a.S_SMOOTH, tT, B, c, Ss);
-    store_mat<M>(a.P_SMOOTH, tT, B, c, Ps);
+    store_vec<M>(a.S_SMOOTH, tT, lay, Ss);
+    store_mat<M>(a.P_SMOOTH, tT, lay, Ps);
     if (GENERIC && a.u_opt_smooth) {
         double z[kNpi];
 #pragma unroll
         for (int k = 0; k < kNpi; k++) z[k] = 0.0;
-        store_u(a.u_opt_smooth, a, tT, c, z);      // column T is never written :95,204
+        store_u(a.u_opt_smooth, a, tT, lay, z);      // column T is never written :95,204
     }
-    if (a.pinv_rank) a.pinv_rank[(size_t)tT * B + c] = -1;
+    if (a.pinv_rank) a.pinv_rank[lay_scalar(tT, lay)] = -1;
 
     int st_guard = 0, st_cap = 0, min_rank = M;
     for (int k = T - 2; k >= 0; k--) {
         const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
         double Sp[M], Pp[M * M], Sm1[M], Pm1[M * M], u_in[kNpi];
-        load_vec<M>(a.S_PLUS, t, B, c, Sp);
-        load_mat<M>(a.P_PLUS, t, B, c, Pp);
-        load_vec<M>(a.S_MINUS, t1, B, c, Sm1);
-        load_mat<M>(a.P_MINUS, t1, B, c, Pm1);
+        load_vec<M>(a.S_PLUS, t, lay, Sp);
+        load_mat<M>(a.P_PLUS, t, lay, Pp);
+        load_vec<M>(a.S_MINUS, t1, lay, Sm1);
+        load_mat<M>(a.P_MINUS, t1, lay, Pm1);
         load_u(a, t, su, u_in);
 
         double J[M * M];
@@ -444,14 +481,14 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
             mat_mul_bt<M>(Pp, A, PAt);                         // P_PLUS * A'
             if (GENERIC) {
                 // pinv(P_MINUS(:,:,k+1)) was computed by eks_pinv (one lane per (chain, step) pair)
-                const int rk = ldg_i(a.rankbuf + (size_t)t1 * B, (unsigned)c * 4u);
+                const int rk = a.rankbuf[lay_scalar(t1, lay)];
                 if (rk < 0) {                                  // non-finite P_MINUS guard :211-213
 #pragma unroll
                     for (int e = 0; e < M * M; e++) J[e] = 0.0;
                     st_guard = 1;
                 } else {
                     double X[M * M];
-                    load_packed<M>(a.X, t1, B, c, X);
+                    load_packed<M>(a.X, t1, lay, X);
                     mat_mul<M>(PAt, X, J);                     // :215
                     rank = rk & 0xff;
                     st_cap |= (rk >> 8) & 1;
@@ -461,7 +498,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
                 mrdivide<M>(PAt, Pm1, J);                      // NewCase...m:132
             }
         }
-        if (a.pinv_rank) a.pinv_rank[(size_t)t * B + c] = rank;
+        if (a.pinv_rank) a.pinv_rank[lay_scalar(t, lay)] = rank;
 
         double Sn[M];
         {
@@ -489,12 +526,12 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
         if (GENERIC) symmetrize<M>(Ps);                        // :226
 #pragma unroll
         for (int i = 0; i < M; i++) Ss[i] = Sn[i];
-        store_vec<M>(a.S_SMOOTH, t, B, c, Ss);
-        store_mat<M>(a.P_SMOOTH, t, B, c, Ps);
+        store_vec<M>(a.S_SMOOTH, t, lay, Ss);
+        store_mat<M>(a.P_SMOOTH, t, lay, Ps);
         if (GENERIC && a.u_opt_smooth) {                       // :229
             double sn_unused[M];
             nlin_state_update<M, FLIP>(p, a.mf, u_in, Ss, sn_unused);
-            store_u(a.u_opt_smooth, a, t, c, u_in);
+            store_u(a.u_opt_smooth, a, t, lay, u_in);
         }
     }
     if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
@@ -567,10 +604,13 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
     // the two sequential sums arrives as a per-chain prefix and the simulated days are added in order
     const bool pre = (d.prefix_days > 0) && J0_prefix && J1_prefix;
     double acc0 = pre ? J0_prefix[c] : 0.0, acc1 = pre ? J1_prefix[c] : 0.0;
+    // u: [K][n_npi][Su], or chain-blocked ((t*nblk + su/blk)*n_npi + k)*blk + su%blk
+    const int ublk = (d.u_block <= 0 || d.u_block >= d.Su) ? d.Su : d.u_block;
+    const size_t unb = (size_t)(d.Su + ublk - 1) / ublk, ucb = (size_t)su / ublk, ucr = (size_t)su % ublk;
     for (int t = 0; t < d.K; t++) {
         double uk[kNpi];
 #pragma unroll
-        for (int k = 0; k < kNpi; k++) uk[k] = (k < d.n_npi) ? u[((size_t)t * d.n_npi + k) * d.Su + su] : 0.0;
+        for (int k = 0; k < kNpi; k++) uk[k] = (k < d.n_npi) ? u[(((size_t)t * unb + ucb) * d.n_npi + k) * ublk + ucr] : 0.0;
         double z1 = 0.0, z2 = 0.0, z3 = 0.0;
         if (d.noise) {
             z1 = z[((size_t)t * 3 + 0) * B + c]; z2 = z[((size_t)t * 3 + 1) * B + c]; z3 = z[((size_t)t * 3 + 2) * B + c];
@@ -679,10 +719,17 @@ static int hip_fail(char *err, hipError_t e, const char *what)
 }
 
 struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, total; };
+static int lane_block_of(const epi_batch_desc *d) { return (d->lane_block <= 0 || d->lane_block >= d->B) ? d->B : d->lane_block; }
+static size_t padded_chains(const epi_batch_desc *d)
+{
+    const int blk = lane_block_of(d);
+    return (size_t)((d->B + blk - 1) / blk) * blk;
+}
 static WsLayout ws_layout(const epi_batch_desc *d)
 {
     const int m = MODEL_TABLE[d->model].m;
-    const size_t nS = (size_t)d->T * m * d->B * sizeof(double), nP = (size_t)d->T * m * m * d->B * sizeof(double);
+    const size_t Bp = padded_chains(d);
+    const size_t nS = (size_t)d->T * m * Bp * sizeof(double), nP = (size_t)d->T * m * m * Bp * sizeof(double);
     WsLayout w{};
     size_t off = 0;
     auto take = [&](bool need, size_t n) { size_t o = off; if (need) off += (n + 255) & ~(size_t)255; return o; };
@@ -692,8 +739,8 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.p_plus = take(!(d->out_mask & EPI_OUT_P_PLUS), nP);
     // smoother intermediates of the generic models: X = pinv(P_MINUS) and its rank word per (step, chain)
     const bool generic = MODEL_TABLE[d->model].generic;
-    w.x = take(generic, (size_t)d->T * (m * (m + 1) / 2) * d->B * sizeof(double));   // packed upper triangle of X
-    w.rank = take(generic, (size_t)d->T * d->B * sizeof(int32_t));
+    w.x = take(generic, (size_t)d->T * (m * (m + 1) / 2) * Bp * sizeof(double));   // packed upper triangle of X
+    w.rank = take(generic, (size_t)d->T * Bp * sizeof(int32_t));
     w.flag = take(generic, 256);
     w.total = off;
     return w;
@@ -980,6 +1027,8 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->phase < 0 || d->phase > 4) { set_err(err, "phase must be 0..4"); return EPI_ERR_BAD_ARG; }
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
     if (d->chunks < -2) { set_err(err, "chunks must be >= -2"); return EPI_ERR_BAD_ARG; }
+    if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
+    if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
 }
@@ -1013,6 +1062,7 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     char *ws = (char *)workspace;
     KArgs ka{};
     ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode; ka.q_mode = d->q_mode;
+    ka.blk = lane_block_of(d); ka.nblk = (d->B + ka.blk - 1) / ka.blk;
     ka.mf.lo_is_zero = mi.lo_is_zero; ka.mf.phi_ge = mi.phi_ge; ka.mf.obs_clamp = mi.obs_clamp;
     ka.mf.obs_type = mi.obs_fixed ? EPI_OBS_NEWCASES : d->obs_type;
     ka.x_series = in->x_series; ka.u_series = in->u_series;
@@ -1105,6 +1155,7 @@ int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_ou
     int rc = epi_ekf_validate(d, err);
     if (rc != EPI_OK) return rc;
     if (!in || !out) { set_err(err, "NULL inputs/outputs"); return EPI_ERR_BAD_ARG; }
+    if (lane_block_of(d) != d->B) { set_err(err, "epi_ekf_run_host takes the classic layout only (lane_block = 0)"); return EPI_ERR_UNSUPPORTED; }
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
     const int m = MODEL_TABLE[d->model].m, mm = m * m;

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(kWave) void rt_expfit_fwd(const RtArgs a)
     if (c >= a.B) return;
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
+    const Lay lay = lay_classic(B, c);   // this function's arrays are plain [T][rows][B]
     auto g = [&](int f) { return a.rp[(size_t)f * B + c]; };
     const RtModel mo = {g(EPI_RT_TIME_SCALE), g(EPI_RT_ALPHA), g(EPI_RT_SIGMA), g(EPI_RT_W_BAR), g(EPI_RT_W_BAR + 1)};
     const double v_bar = g(EPI_RT_V_BAR), beta = g(EPI_RT_BETA_EKF), gamma = g(EPI_RT_GAMMA_EKF);
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(kWave) void rt_expfit_fwd(const RtArgs a)
     double xk = a.x[sx];
     for (int k = 0; k < T; k++) {
         const double xn = (k + 1 < T) ? a.x[(size_t)(k + 1) * a.Sx + sx] : 0.0;   // next step's input, ahead of the stores
-        store_vec<2>(a.S_MINUS, k, B, c, sm);                   // :37-38
-        store_mat<2>(a.P_MINUS, k, B, c, Pm);
+        store_vec<2>(a.S_MINUS, k, lay, sm);                   // :37-38
+        store_mat<2>(a.P_MINUS, k, lay, Pm);
         // ObsHessianTerms :202-227: Gs = Gv = {0}, so gs, Gsp, gv, Gvp are 0 for either order
         const double xk_minus = ((sm[0] + v_bar) + 0.0) + 0.0;  // :52
         double innov, K[2], sp[2], Pp[4];
@@ -126,9 +127,9 @@ __global__ __launch_bounds__(kWave) void rt_expfit_fwd(const RtArgs a)
 #pragma unroll
             for (int e = 0; e < 4; e++) Pm[e] = ((T2[e] + T3[e]) + Fsp[e]) + Fwp[e];   // :83
         }
-        store_vec<2>(a.S_PLUS, k, B, c, sp);                    // :86-88
-        store_mat<2>(a.P_PLUS, k, B, c, Pp);
-        store_vec<2>(a.K_GAIN, k, B, c, K);
+        store_vec<2>(a.S_PLUS, k, lay, sp);                    // :86-88
+        store_mat<2>(a.P_PLUS, k, lay, Pp);
+        store_vec<2>(a.K_GAIN, k, lay, K);
         if (a.innovations) a.innovations[(size_t)k * B + c] = innov;
         // :91-101  windows are newest-first and summed front to back
         const int cnt = (k + 1 < L) ? (k + 1) : L;
@@ -153,19 +154,20 @@ __global__ __launch_bounds__(256) void rt_expfit_bwd(const RtArgs a)
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.B) return;
     const int B = a.B, T = a.T;
+    const Lay lay = lay_classic(B, c);
     auto g = [&](int f) { return a.rp[(size_t)f * B + c]; };
     const RtModel mo = {g(EPI_RT_TIME_SCALE), g(EPI_RT_ALPHA), g(EPI_RT_SIGMA), g(EPI_RT_W_BAR), g(EPI_RT_W_BAR + 1)};
     double Ss[2], Ps[4];
-    load_vec<2>(a.S_PLUS, T - 1, B, c, Ss);
-    load_mat<2>(a.P_PLUS, T - 1, B, c, Ps);
-    store_vec<2>(a.S_SMOOTH, T - 1, B, c, Ss);
-    store_mat<2>(a.P_SMOOTH, T - 1, B, c, Ps);
+    load_vec<2>(a.S_PLUS, T - 1, lay, Ss);
+    load_mat<2>(a.P_PLUS, T - 1, lay, Ps);
+    store_vec<2>(a.S_SMOOTH, T - 1, lay, Ss);
+    store_mat<2>(a.P_SMOOTH, T - 1, lay, Ps);
     for (int k = T - 2; k >= 0; k--) {
         double sp[2], Pp[4], Sm1[2], Pm1[4];
-        load_vec<2>(a.S_PLUS, k, B, c, sp);
-        load_mat<2>(a.P_PLUS, k, B, c, Pp);
-        load_vec<2>(a.S_MINUS, k + 1, B, c, Sm1);
-        load_mat<2>(a.P_MINUS, k + 1, B, c, Pm1);
+        load_vec<2>(a.S_PLUS, k, lay, sp);
+        load_mat<2>(a.P_PLUS, k, lay, Pp);
+        load_vec<2>(a.S_MINUS, k + 1, lay, Sm1);
+        load_mat<2>(a.P_MINUS, k + 1, lay, Pm1);
         double A[4], E, tnh, omt, T1[4], J[4], D[4], T2[4];
         rt_jacobian(mo, sp, A, E, tnh, omt);
         mat_mul_bt<2>(Pp, A, T1);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void rt_expfit_bwd(const RtArgs a)
         mat_mul<2>(J, D, T1); mat_mul_bt<2>(T1, J, T2);
 #pragma unroll
         for (int e = 0; e < 4; e++) Ps[e] = Pp[e] - T2[e];
-        store_vec<2>(a.S_SMOOTH, k, B, c, Ss);
-        store_mat<2>(a.P_SMOOTH, k, B, c, Ps);
+        store_vec<2>(a.S_SMOOTH, k, lay, Ss);
+        store_mat<2>(a.P_SMOOTH, k, lay, Ps);
     }
 }

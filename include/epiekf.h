@@ -126,6 +126,13 @@ typedef struct epi_batch_desc {
                              waves beyond a whole number of one-wave-per-SIMD rounds form the second chunk);
                              -2: "pipelined halves" (generic models, path_hint = 1): the second half's forward
                              kernel and the first half's eks_pinv grid share the SIMDs */
+    int32_t lane_block;   /* layout of the OUTPUT arrays (and of the workspace) of epi_ekf_run_device.  0 or >= B: the
+                             classic [T][rows][B].  blk in 1..B-1 (8 recommended): chain-blocked,
+                             element (t, row, c) at ((t*nblk + c/blk)*rows + row)*blk + c%blk, nblk = ceil(B/blk) --
+                             the rows of blk neighbouring chains form one contiguous block, which is what HBM wants
+                             to see from ~100 concurrent stores per wave; arrays are then sized for
+                             nblk*blk chains and one-row arrays (innovations, rho, pinv_rank) are [T][nblk*blk].
+                             Inputs are never blocked.  epi_ekf_run_host accepts the classic layout only. */
 } epi_batch_desc;
 
 typedef struct epi_inputs {
@@ -174,6 +181,8 @@ typedef struct epi_sim_desc {
     int32_t noise;    /* 0: noise-free; 1: z given [K][3][B] standard normal draws */
     int32_t with_cost;/* 1: also J0/J1 of NPICost over the simulated span */
     int32_t prefix_days; /* epi_sialpha_score_device: days already summed into J0_prefix / J1_prefix */
+    int32_t u_block;  /* 0 or >= Su: u is [K][n_npi][Su]; otherwise u is chain-blocked like an output of
+                         epi_ekf_run_device with lane_block = u_block (u_opt_smooth fed straight into the scoring) */
 } epi_sim_desc;
 
 /* SIalpha_Controlled.m:1-32 batched.  sp [EPI_SIM_PRM_COUNT][B]; u [K][n_npi][Su];
