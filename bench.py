@@ -259,7 +259,10 @@ def main():
                        "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather of (J0, J1) to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args), "kernel": dom,
-                         "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes},
+                         "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes,
+                         "limiter": {"ekf_fwd": "HBM writes (store pattern) + lone-wave latency",
+                                     "eks_pinv": "fp64 VALU issue (Jacobi; 92 % VALU-active at 2 waves/SIMD) -- not HBM",
+                                     "eks_bwd": "lone-wave latency + HBM"}[dom]},
             "kernels": {**{k + "_ms": v for k, v in ms.items()},
                         **{k + "_GBs": alg[k] * steps_per_pass / (ms[k] * 1e-3) / 1e9 for k in ms},
                         "whole_step_algorithmic_bytes": step_bytes, "whole_step_GBs": step_gbs,
