@@ -53,8 +53,9 @@ def parse():
                          "stream, one launch per kernel and pass, so that rocprofv3's per-kernel averages and the HIP-event "
                          "averages of this script describe the same launches; -1 = whole one-wave-per-SIMD rounds + a tail "
                          "chunk whose kernels run beside the main chunk's eks_pinv grid (about 1 ms per pass faster)")
-    ap.add_argument("--lane-block", type=int, default=8,
-                    help="output layout (epi_batch_desc.lane_block): 8 = chain-blocked (default), 0 = classic [T][rows][B]")
+    ap.add_argument("--lane-block", type=int, default=-1,
+                    help="output layout (epi_batch_desc.lane_block): -1 = chain-blocked with one block per wavefront of the "
+                         "launch (epi_ekf_preferred_lane_block; default), n > 0 = blocks of n chains, 0 = classic [T][rows][B]")
     ap.add_argument("--no-score", action="store_true",
                     help="skip the scenario-scoring tail (SIalpha_Controlled + NPICost on the horizon) after each pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,7 +154,7 @@ def main():
     m = w.m
     outputs = None if args.outputs == "all" else ["u_opt_smooth", "S_SMOOTH"]
     dw = batch.DeviceWorkload(w, dev)
-    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks, lane_block=args.lane_block)
+    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks, lane_block="auto" if args.lane_block < 0 else args.lane_block)
     steps_per_pass = w.B * w.T
     t_hist_idx = w.meta.get("T_hist", w.T) - 1
 
@@ -252,7 +253,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "chunks": args.chunks,
-                       "lane_block": args.lane_block,
+                       "lane_block": runner.blk,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
                        "scoring_tail": bool(score),

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
-    "epi_ekf_precheck_device", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
+    "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_calib_copy_f64_device",
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
     "epi_preprocess_workspace_bytes", "epi_preprocess_device", "epi_nnls_affine_fit_device",
@@ -125,6 +125,8 @@ def lib():
         h.epi_ekf_precheck_device.restype = C.c_int
         h.epi_ekf_precheck_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.c_void_p, C.POINTER(C.c_int),
                                               C.c_char_p]
+        h.epi_ekf_preferred_lane_block.restype = C.c_int
+        h.epi_ekf_preferred_lane_block.argtypes = [C.POINTER(BatchDesc)]
         h.epi_ekf_run_device.restype = C.c_int
         h.epi_ekf_run_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_char_p]

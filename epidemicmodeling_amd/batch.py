@@ -66,7 +66,7 @@ class EkfRunner:
         (chain, step)-parallel pinv grid with the sequential kernels of the other chunks).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
         run() enqueues only the variant that will actually execute.  lane_block: 0 = classic [T][rows][B] outputs;
-        8 = chain-blocked outputs (epi_batch_desc.lane_block): `out` then holds the raw blocked tensors
+        8 / "auto" (= chains per wavefront of the launch) = chain-blocked outputs (epi_batch_desc.lane_block): `out` then holds the raw blocked tensors
         [T, nblk, rows, blk] ([T, nblk*blk] for one-row arrays) and unblocked() returns [T, rows, B] copies."""
         self.dw = dw
         names = list(OUT_NAMES) if outputs is None else list(outputs)
@@ -76,6 +76,8 @@ class EkfRunner:
         self.mask = out_mask_of(names)
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
                                    dw.r_mode, self.mask, dw.q_mode)
+        if lane_block == "auto":       # one block per wavefront of the launch
+            lane_block = int(_lib.lib().epi_ekf_preferred_lane_block(C.byref(self.desc)))
         self.blk = dw.B if (lane_block <= 0 or lane_block >= dw.B) else int(lane_block)
         self.nblk = (dw.B + self.blk - 1) // self.blk
         self.desc.lane_block = 0 if self.blk == dw.B else self.blk

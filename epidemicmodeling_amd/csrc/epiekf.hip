@@ -1039,6 +1039,16 @@ size_t epi_ekf_workspace_bytes(const epi_batch_desc *d)
     return ws_layout(d).total;
 }
 
+int epi_ekf_preferred_lane_block(const epi_batch_desc *d)
+{
+    epi_batch_desc probe;
+    if (!d) return 0;
+    probe = *d; probe.lane_block = 0;
+    if (epi_ekf_validate(&probe, nullptr) != EPI_OK) return 0;
+    const int lw = balanced_lanes(d->B, MODEL_TABLE[d->model].m == 6 ? 1 : 2);
+    return lw < d->B ? lw : d->B;
+}
+
 int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
                        void *workspace, size_t workspace_bytes, void *stream, char *err)
 {

@@ -160,6 +160,12 @@ size_t epi_ekf_workspace_bytes(const epi_batch_desc *d);        /* device scratc
 /* Synchronous: inspects Ps_init / Q (device pointers) and reports in *fast_ok whether path_hint = 1 is valid. */
 int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err);
 
+/* The lane_block that matches the way epi_ekf_run_device will launch this batch on the current device: the number of
+ * chains one wavefront handles (64, or fewer when the launch is split into equally full rounds).  With it every
+ * wavefront's loads and stores of a step are one contiguous piece per array -- the fastest of the blocked layouts
+ * (DESIGN.md 3).  Returns 0 for an invalid descriptor. */
+int epi_ekf_preferred_lane_block(const epi_batch_desc *d);
+
 /* All pointers in `in`/`out`/`workspace` are DEVICE pointers on the current HIP
  * device; `stream` is a hipStream_t (NULL = default stream).  Asynchronous:
  * returns after enqueueing.  Outputs not selected in out_mask may be NULL. */

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from epidemicmodeling_amd import batch, synth  # noqa: E402
 
 phase = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 15
-r = batch.EkfRunner(batch.DeviceWorkload(synth.make_cfg4(), "cuda:0"), lane_block=int(os.environ.get("EPI_LANE_BLOCK", "0")))
+r = batch.EkfRunner(batch.DeviceWorkload(synth.make_cfg4(), "cuda:0"), lane_block=(lambda v: "auto" if v == "auto" else int(v))(os.environ.get("EPI_LANE_BLOCK", "auto")))
 for ph in (1, 3, 4):
     r.run(phase=ph)
 torch.cuda.synchronize()

@@ -30,7 +30,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 del src, dst
 w = synth.make_cfg4()
-r = batch.EkfRunner(batch.DeviceWorkload(w, dev), lane_block=8)   # bench.py's default layout
+r = batch.EkfRunner(batch.DeviceWorkload(w, dev), lane_block="auto")   # bench.py's default layout
 for _ in range(2):
     for ph in (1, 3, 4):
         r.run(phase=ph)
