@@ -445,6 +445,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     // results) and consumed one iteration later, so that a lone wave does not sit through a full memory round trip
     // at the start of every step
     constexpr int PF = (M == 6) ? EPI_BWD_PREFETCH : 0;   // the 3-state kernel would drop from two waves per SIMD to one
+    constexpr bool RC = (M == 3) || EPI_BWD_RECOMPUTE;    // ... and has the registers to recompute s(k+1|k), P(k+1|k)
     BwdIn<M> nxt;
     auto step = [&](int k) {
         const int t = tpos<FLIP>(k, T);
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         // s(k|k), P(k|k), u(:,k) with the forward kernel's own functions (:155-164) -- bit-identical either way
         double A[M * M], Sm1[M];
         state_jacobians<M, FLIP>(p, cur.u, cur.Sp, A);         // :206 (and :157 of the forward pass)
-        if (EPI_BWD_RECOMPUTE) {
+        if (RC) {
             double u_app[kNpi];
 #pragma unroll
             for (int q = 0; q < kNpi; q++) u_app[q] = cur.u[q];
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             // (see ekf_fwd_sym)
             // (P(k+1|k) is formed only now, after X has been consumed by J: the two are never live together)
             double Dsym[NS];
-            if (EPI_BWD_RECOMPUTE) predict_cov_sym<M>(A, cur.Pp, Qd, Dsym);
+            if (RC) predict_cov_sym<M>(A, cur.Pp, Qd, Dsym);
             else load_sym<M>(a.P_MINUS, tpos<FLIP>(k + 1, T), lay, Dsym);
 #pragma unroll
             for (int e = 0; e < NS; e++) Dsym[e] = Dsym[e] - Ps[e];
