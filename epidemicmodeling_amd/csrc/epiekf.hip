@@ -415,8 +415,19 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
-    ChainPrm p;
-    load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero);
+    // the four 12-vectors of `params` in an LDS column per lane instead of 96 VGPRs (without this the 6-state kernel
+    // spills: 512 registers + 84 B of scratch)
+    __shared__ double vlds[4 * kNpi * kWave];
+    LitePrm<VecLds> p;
+    load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
+    p.v.base = vlds + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) {
+        vlds[(0 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_A + k) * B + c];
+        vlds[(1 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
+        vlds[(2 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
+        vlds[(3 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+    }
 
     // terminal conditions :189-202
     double Ss[M], Ps[M * M];
