@@ -34,5 +34,6 @@ def run(mode, lb, label):
 
 run(0, 0, "[t][row][B]")
 run(1, 0, "[t][B/40][row][40]")
+run(3, 0, "[t][B/40][row/2][40][2] 16B")
 for lb in (8, 16, 32, 64, 128, 256):
     run(2, lb, f"[t][B/{lb}][row][{lb}]")
