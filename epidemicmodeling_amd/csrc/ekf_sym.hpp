@@ -11,7 +11,7 @@
 //    to Inf/NaN can differ from the dense evaluation in WHERE the non-finite values sit (both are
 //    garbage there; status bit 0 / the J = 0 guard of :211 still fire) -- DESIGN.md "Arithmetic contract";
 //  * the smoother keeps the four 12-vectors of `params` in an LDS column per lane instead of 96 VGPRs.
-// Net effect for m = 6: about half the fp64 operations and 380-410 instead of 494-512 VGPRs (no scratch); still
+// Net effect for m = 6: about half the fp64 operations and 300-370 instead of 470-512 VGPRs (no scratch); still
 // one wave per SIMD -- see DESIGN.md "Occupancy and the wave-count quantum" for what was tried to get to two.
 #pragma once
 
@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
 #endif
 #ifndef EPI_BWD_LB
 #define EPI_BWD_LB kWave
+#endif
 // Two knobs of the packed smoother, settled by A/B runs on the headline sweep (profiles/ab_phase.py 4, medians):
 //   EPI_BWD_PREFETCH  what is requested one step ahead (bit 0: state, controls, rank word; bit 1: P_PLUS; bit 2: X)
 //   EPI_BWD_RECOMPUTE 1: s(k+1|k), P(k+1|k) are recomputed from the stored s(k|k), P(k|k), u with the forward kernel's
@@ -103,7 +104,6 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
 #endif
 #ifndef EPI_BWD_RECOMPUTE
 #define EPI_BWD_RECOMPUTE 0
-#endif
 #endif
 constexpr int kPipeLanes = 40;   // lanes per workgroup of the LP = 1 forward variant
 // where the forward kernel keeps the model constants (see ekf_fwd_sym)
