@@ -127,9 +127,9 @@ def prescribe(cases, deaths, population, ip, horizon=30, n_eps=50, num_regressio
     u_nan = np.concatenate([u, np.full((horizon, n, S), np.nan)])
     w6 = workload6(xh, Rh, u_nan, N, I0, fit2["a"], fit2["b"], eps_grid)
     dw = batch.DeviceWorkload(w6, device)
-    runner = batch.EkfRunner(dw, outputs=["u_opt_smooth", "S_SMOOTH"])
+    runner = batch.EkfRunner(dw, outputs=["u_opt_smooth", "S_SMOOTH"], lane_block="auto")   # chain-blocked outputs
     runner.run()
-    uos = runner.out["u_opt_smooth"]                                                   # [T+H, n, S*n_eps], stays in HBM
+    uos = runner.out["u_opt_smooth"]                                                   # stays in HBM (blocked layout)
     # scoring (:481-493): simulate the horizon from the end-of-history state, NPICost over [historic, horizon]
     wts = np.ones((n, S)) if npi_weights is None else np.asarray(npi_weights, dtype=np.float64)
     rr = np.repeat(np.arange(S), n_eps)
@@ -142,13 +142,18 @@ def prescribe(cases, deaths, population, ip, horizon=30, n_eps=50, num_regressio
     sp[batch.SIM_W:batch.SIM_W + n] = wts[:, rr]
     J0p = np.cumsum(hist[:, 0] * hist[:, 1] * hist[:, 2], axis=0)[-1][rr]              # sequential historic sums
     J1p = np.cumsum((wts[None] * u).reshape(T * n, S), axis=0)[-1][rr]
-    sc = batch.score_sweep(uos, T, sp, J0p, J1p)
+    sc = batch.score_sweep(uos, T, sp, J0p, J1p, B=S * n_eps)
     front, i_opt = batch.pareto_front(sc["J0"], sc["J1"], S)
     torch.cuda.synchronize(dw.device)
     i_opt_h = i_opt.cpu().numpy()
-    chains = torch.as_tensor(np.arange(S) * n_eps + i_opt_h, device=uos.device)
+    chains = np.arange(S) * n_eps + i_opt_h
+    if uos.dim() == 4:            # blocked [T+H, nblk, n, blk]: pick (block, lane) of every optimum chain
+        cb = torch.as_tensor(chains // runner.blk, device=uos.device); cr = torch.as_tensor(chains % runner.blk, device=uos.device)
+        best = uos[T:][:, cb, :, cr].permute(1, 2, 0)          # index dims come first: [S, H, n] -> [H, n, S]
+    else:
+        best = uos[T:].index_select(2, torch.as_tensor(chains, device=uos.device))
     out.update(eps_grid=eps_grid, sp=sp, J0_prefix=J0p, J1_prefix=J1p,
                J0=sc["J0"].cpu().numpy().reshape(S, n_eps), J1=sc["J1"].cpu().numpy().reshape(S, n_eps),
                front=front.cpu().numpy(), i_opt=i_opt_h, sweep=w6,
-               prescription=uos[T:].index_select(2, chains).cpu().numpy())
+               prescription=best.cpu().numpy())
     return out
