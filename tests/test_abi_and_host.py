@@ -211,3 +211,23 @@ def test_rt_expfit_validate_and_tools_errors(hip_lib):
         tools.Rt_ExpFitEKF(np.ones((1, 5)), [1.0, 0.0], [1, 0.9, 0.1], [0, 0], 0, np.eye(2), np.eye(2), 1.0, 0.9, 0.995, 21, 0)
     with pytest.raises(IndexError):                              # params(3) on a 2-vector
         tools.Rt_ExpFitEKF(np.ones((1, 5)), [1.0, 0.0], [1, 0.9], [0, 0], 0, np.eye(2), np.eye(2), 1.0, 0.9, 0.995, 21, 1)
+
+
+def test_mex_gateways_compile_against_the_abi_header():
+    """matlab/*.cpp are shipped as source (no MATLAB in the build image): at least they must be valid C++ against
+    include/epiekf.h and the documented MEX API signatures (tests/mex_stub/mex.h is a declarations-only stand-in)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if not cxx:
+        pytest.skip("no g++")
+    for f in ("epiekf_mex.cpp", "epiekf_rt_mex.cpp"):
+        r = subprocess.run([cxx, "-std=c++11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                            "-I" + os.path.join(H.ROOT, "tests", "mex_stub"), "-I" + os.path.join(H.ROOT, "include"),
+                            os.path.join(H.ROOT, "matlab", f)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    # plain C consumers see the same header
+    r = subprocess.run([shutil.which("gcc") or "gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
+                        "-I" + os.path.join(H.ROOT, "include"), "-x", "c", "-"], input='#include "epiekf.h"\nint main(void){return epi_abi_version == 0;}\n',
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
