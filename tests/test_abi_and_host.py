@@ -228,6 +228,6 @@ def test_mex_gateways_compile_against_the_abi_header():
         assert r.returncode == 0, r.stderr
     # plain C consumers see the same header
     r = subprocess.run([shutil.which("gcc") or "gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
-                        "-I" + os.path.join(H.ROOT, "include"), "-x", "c", "-"], input='#include "epiekf.h"\nint main(void){return epi_abi_version == 0;}\n',
+                        "-I" + os.path.join(H.ROOT, "include"), "-x", "c", "-"], input='#include "epiekf.h"\nint main(void){epi_batch_desc d; d.lane_block = 0; return d.lane_block + (int)sizeof(epi_outputs) * 0;}\n',
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
