@@ -17,6 +17,9 @@ double mxGetScalar(const mxArray *pa);
 size_t mxGetM(const mxArray *pa);
 size_t mxGetN(const mxArray *pa);
 size_t mxGetNumberOfElements(const mxArray *pa);
+mwSize mxGetNumberOfDimensions(const mxArray *pa);
+const mwSize *mxGetDimensions(const mxArray *pa);
+void *mxGetData(const mxArray *pa);
 mxArray *mxCreateDoubleMatrix(mwSize m, mwSize n, mxComplexity flag);
 mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID classid, mxComplexity flag);
 mxArray *mxCreateStructMatrix(mwSize m, mwSize n, int nfields, const char **fieldnames);
