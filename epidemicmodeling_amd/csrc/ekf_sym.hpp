@@ -53,7 +53,8 @@ EPI_DEV void load_sym(const double *__restrict__ src, int t, const Lay &l, doubl
 }
 
 // ---------------------------------------------------------------------------
-// pre-check: may this batch take the symmetric fast path?  (Ps_init and Ps_final bit-wise symmetric, Q_w diagonal)
+// pre-check: may this batch take the symmetric fast path?  (Ps_init and Ps_final bit-wise symmetric, Q_w diagonal,
+// s_init / Ps_init / Q_w finite)
 // ---------------------------------------------------------------------------
 template <int M>
 __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restrict__ flag, int force_dense)
@@ -76,6 +77,16 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
             const bool fsame = (fu == fl) || (is_nan(fu) && is_nan(fl));
             dense = dense || !same || !fsame || !(qu == 0.0) || !(ql == 0.0);
         }
+    // a non-finite entry in the initial state, the initial covariance or the process noise (e.g. the NaN "free end
+    // point" markers handed to a time-flipped wrapper as its initial condition): the packed kernels skip products with
+    // structural zeros, which is exact only for finite operands -- such a batch mirrors the oracle through the dense
+    // kernels instead
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        dense = dense || is_nonfinite(a.s_init[(size_t)i * B + c]) || is_nonfinite(a.Q[(size_t)IXM(i, i) * B + c]);
+#pragma unroll
+        for (int j = i; j < M; j++) dense = dense || is_nonfinite(a.Ps_init[(size_t)IXM(i, j) * B + c]);
+    }
     if (dense) atomicOr(flag, 1);
 }
 

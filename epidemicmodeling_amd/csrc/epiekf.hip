@@ -1144,7 +1144,7 @@ int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void 
 {
     int rc = epi_ekf_validate(d, err);
     if (rc != EPI_OK) return rc;
-    if (!in || !fast_ok || !in->Ps_init || !in->Ps_final || !in->Q) { set_err(err, "NULL argument"); return EPI_ERR_BAD_ARG; }
+    if (!in || !fast_ok || !in->Ps_init || !in->Ps_final || !in->Q || !in->s_init || !in->s_final) { set_err(err, "NULL argument"); return EPI_ERR_BAD_ARG; }
     const ModelInfo &mi = MODEL_TABLE[d->model];
     *fast_ok = 0;
     if (!mi.generic || d->q_mode != 0) return EPI_OK;   // NewCase models never symmetrise; Q(:,:,k): dense kernels only
@@ -1152,6 +1152,7 @@ int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void 
     ka.B = d->B;
     ka.Ps_init = mi.flipped ? in->Ps_final : in->Ps_init;
     ka.Ps_final = mi.flipped ? in->Ps_init : in->Ps_final;
+    ka.s_init = mi.flipped ? in->s_final : in->s_init;
     ka.Q = in->Q;
     int *flag = nullptr;
     hipError_t e = hipMalloc((void **)&flag, sizeof(int));
