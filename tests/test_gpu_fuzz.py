@@ -223,3 +223,34 @@ def test_random_scenarios_match_the_oracle(gpu_device, data):
                       *[dp(v) for v in res])
         for q in range(5):
             assert np.array_equal(out[:, q, c], res[q]), (B, Ks, dt, c, q)
+
+
+@settings(max_examples=_N or 40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=not _N)
+@given(st.data())
+def test_random_rt_expfit_matches_the_oracle(gpu_device, data):
+    """Random Rt_ExpFitEKF problems (both orders, gaps, forecast tails, monitor lengths, noise settings, shared series):
+    1e-9 relative per output row against the oracle (device exp/tanh vs libm: not bit-exact by construction)."""
+    from epidemicmodeling_amd import batch, synth
+    from oracle import oracle_lib as olib
+    draw = data.draw
+    order = draw(st.sampled_from([1, 2])); S = draw(st.integers(1, 8)); T = draw(st.integers(16, 80))
+    nd = draw(st.sampled_from([1, 1, 3])); L = draw(st.integers(1, 30)); hor = draw(st.integers(0, 10))
+    w = synth.make_rt(S, T, n_draws=nd, order=order, horizon=hor, seed=draw(st.integers(0, 10 ** 6)),
+                      w_bar=draw(st.sampled_from([(0.0, 0.0), (0.5, 1e-4), (-2.0, -1e-3)])), L=L)
+    cut = draw(st.integers(1, T))
+    w.x = np.ascontiguousarray(w.x[:cut])
+    rng = np.random.default_rng(draw(st.integers(0, 10 ** 6)))
+    if draw(st.booleans()):
+        w.x[rng.random(w.x.shape) < 0.15] = np.nan
+    w.rp = w.rp.copy()
+    w.rp[7] = draw(st.sampled_from([0.9, 1.0, 0.5])); w.rp[8] = draw(st.sampled_from([0.995, 1.0, 0.9]))
+    w.rp[1] = draw(st.sampled_from([0.9, 1.0, 0.3])); w.rp[2] = draw(st.sampled_from([0.1, 1.0, 0.01]))
+    got = batch.rt_expfit(w, gpu_device)
+    ref = olib.rt_expfit_batch(w.x, w.rp, w.L, order, x_series=w.x_series)
+    for n in ref:
+        g, r = got[n], ref[n]
+        if g.ndim == 3:
+            for row in range(g.shape[1]):
+                assert H.rel_err(g[:, row], r[:, row]) <= 1e-9, (order, cut, S, L, n, row, H.rel_err(g[:, row], r[:, row]))
+        else:
+            assert H.rel_err(g, r) <= 1e-9, (order, cut, S, L, n)
