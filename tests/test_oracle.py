@@ -493,3 +493,44 @@ def test_oracle_reproduces_aux_golden_vectors():
     for r in range(g["in_J0"].shape[0]):
         on, io = olib.pareto_front(g["in_J0"][r], g["in_J1"][r])
         assert np.array_equal(on, g["out_on_front"][r]) and io == g["out_i_opt"][r]
+
+
+# ---------------------------------------------------------------- property-based: two readings of the .m files
+def test_random_problems_c_oracle_vs_numpy_restatement():
+    """hypothesis: random model variants / sizes / gaps / free controls / monitor lengths / noise settings -- the C oracle
+    and the NumPy (LAPACK) restatement agree on every forward quantity to 1e-9 and on the pinv truncation ranks."""
+    from hypothesis import HealthCheck, given, settings, strategies as st
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+    @given(st.data())
+    def run(data):
+        draw = data.draw
+        kind = draw(st.sampled_from(["sia3", "sia6", "sia3_bwd", "sia6_bwd", "newcase", "newcase_codegen"]))
+        T = draw(st.integers(3, 30)); hor = draw(st.integers(0, 6))
+        if kind == "sia3":
+            w = synth.make_cfg3(2, T + hor)
+        elif kind == "sia6":
+            w = synth.make_cfg4(1, 2, T, hor)
+        elif kind == "sia3_bwd":
+            w = synth.as_backward(synth.make_cfg3(2, T + hor))
+        elif kind == "sia6_bwd":
+            w = synth.as_backward(synth.make_cfg4(1, 2, T, 0))
+        else:
+            w = synth.make_row4(2, T + hor + 2, min(hor, T), codegen=(kind == "newcase_codegen"))
+        rng = np.random.default_rng(draw(st.integers(0, 10 ** 6)))
+        w.L = draw(st.integers(1, 25))
+        if draw(st.booleans()):
+            w.x = w.x.copy(); w.x[rng.random(w.x.shape) < 0.2] = np.nan
+        if w.m == 6 and draw(st.booleans()):
+            w.u = w.u.copy(); w.u[rng.random(w.u.shape) < 0.2] = np.nan
+        w.prm = w.prm.copy()
+        w.prm[L.PRM_BETA_EKF] = draw(st.sampled_from([1.0, 0.9])); w.prm[L.PRM_GAMMA_EKF] = draw(st.sampled_from([1.0, 0.995]))
+        ob = H.oracle_batch(w)
+        for c in range(w.B):
+            nd = H.numpy_chain(w, c)
+            for n in FWD:
+                assert H.rel_err(H.batch_chain(ob, n, c, w.m), nd[n]) <= 1e-9, (kind, T, c, n)
+            if "pinv_rank" in nd:
+                assert np.array_equal(nd["pinv_rank"], ob["pinv_rank"][:, c]), (kind, T, c)
+
+    run()
