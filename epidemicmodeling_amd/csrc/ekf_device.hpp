@@ -353,6 +353,12 @@ EPI_DEV void jacobi_rot(double &x, double &y, double s, double tau)
     y = fma(s, fma(-h, tau, g), h);
 }
 
+EPI_DEV bool jacobi_left_alone(bool dead_p, bool dead_q, double dp, double dq, double apq)
+{
+    const double dl = fabs(dead_p ? dq : dp);   // the live entry of a mixed pair
+    return (dead_p && dead_q) || (dead_p != dead_q && (dl + 100.0 * fabs(apq)) == dl);
+}
+
 // a: symmetric, only the upper triangle (i <= j) is read/updated.  Returns true if the sweep cap was hit.
 template <int M>
 EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
@@ -366,10 +372,10 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
     for (int i = 0; i < M; i++) { b[i] = d[i] = a[IXM(i, i)]; z[i] = 0.0; }
     bool capped = true;
     for (int sweep = 1; sweep <= kJacobiMaxSweeps; sweep++) {
-        // sym_pinv discards every eigenpair below tol = M*eps(max|d|).  A pair of indices whose diagonal entries are
-        // BOTH below 2^-10 of that cut-off only mixes directions that are discarded anyway: such pairs are neither
-        // rotated nor counted in the convergence sum (same rule as the oracle; X changes by ~1e-20 relative, the
-        // rotations by -15 %)
+        // sym_pinv discards every eigenpair below tol = M*eps(max|d|); an index is "dead" when its diagonal entry is
+        // below 2^-10 of that cut-off.  Left alone (not rotated, zeroed or counted in the convergence sum; same rule
+        // as the oracle): pairs of two dead indices, and dead/live pairs whose 100|a_pq| vanishes against the live
+        // diagonal entry.  X changes by <1e-18 relative, the rotations by -30 %.
         double dmax = 0.0;
 #pragma unroll
         for (int i = 0; i < M; i++) dmax = fmax(dmax, fabs(d[i]));
@@ -381,7 +387,7 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
 #pragma unroll
         for (int p = 0; p < M - 1; p++)
 #pragma unroll
-            for (int q = p + 1; q < M; q++) sm = (dead[p] && dead[q]) ? sm : sm + fabs(a[IXM(p, q)]);
+            for (int q = p + 1; q < M; q++) sm = jacobi_left_alone(dead[p], dead[q], d[p], d[q], a[IXM(p, q)]) ? sm : sm + fabs(a[IXM(p, q)]);
         if (sm == 0.0) { capped = false; break; }
         const double tresh = (sweep < 4) ? 0.2 * sm / (double)(M * M) : 0.0;
 #pragma unroll
@@ -394,7 +400,7 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
                 // which leaves every operand bit-wise unchanged) for the lanes that do not rotate.
                 const double apq = a[IXM(p, q)];
                 const double g = 100.0 * fabs(apq);
-                const bool live = !(dead[p] && dead[q]);
+                const bool live = !jacobi_left_alone(dead[p], dead[q], d[p], d[q], apq);
                 const bool negl = live && sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q]);
                 const bool rot = live && !negl && (fabs(apq) > tresh);
                 if (__builtin_amdgcn_ballot_w64(rot) != 0ull) {

@@ -107,25 +107,32 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
         z[i] = 0.0;
     }
     for (int sweep = 1; sweep <= ORC_JACOBI_MAX_SWEEPS; sweep++) {
-        /* The caller (orc_sym_pinv) discards every eigenpair below tol = m*eps(max|d|).  A pair of indices whose
-         * diagonal entries are BOTH below 2^-10 of that cut-off only mixes directions that are discarded anyway:
-         * such pairs are neither rotated nor counted in the convergence sum (their couplings to the kept directions
-         * are still rotated away).  X changes by ~1e-20 relative, the work by -15 %. */
+        /* The caller (orc_sym_pinv) discards every eigenpair below tol = m*eps(max|d|).  Call an index "dead" when
+         * its diagonal entry is below 2^-10 of that cut-off.  Two kinds of pairs are left alone (neither rotated,
+         * zeroed nor counted in the convergence sum):
+         *   - both indices dead: the rotation only mixes directions that are discarded anyway;
+         *   - one dead, one live, and 100|a_pq| vanishes against the live diagonal entry: the rotation angle is
+         *     below eps/100, so the live eigenpair would not move; only the dead entry's relative accuracy is at
+         *     stake, and that entry is discarded.
+         * X changes by <1e-18 relative, the rotations by -30 %. */
         double dmax = 0.0;
         for (int i = 0; i < m; i++) dmax = fmax(dmax, fabs(d[i]));
         const double cut = ((double)m * eps_of(dmax)) * 0x1p-10;
         int dead[MM];
         for (int i = 0; i < m; i++) dead[i] = skip_dead && (fabs(d[i]) < cut);
+#define JACOBI_LEFT_ALONE(p, q, apq)                                                                      \
+    ((dead[p] && dead[q]) ||                                                                              \
+     (dead[p] != dead[q] && (fabs(d[dead[p] ? (q) : (p)]) + 100.0 * fabs(apq)) == fabs(d[dead[p] ? (q) : (p)])))
         double sm = 0.0;
         for (int p = 0; p < m - 1; p++)
             for (int q = p + 1; q < m; q++)
-                if (!(dead[p] && dead[q])) sm = sm + fabs(a[IX(p, q, m)]);
+                if (!JACOBI_LEFT_ALONE(p, q, a[IX(p, q, m)])) sm = sm + fabs(a[IX(p, q, m)]);
         if (sm == 0.0) break;
         double tresh = (sweep < 4) ? 0.2 * sm / (double)(m * m) : 0.0;
         for (int p = 0; p < m - 1; p++)
             for (int q = p + 1; q < m; q++) {
-                if (dead[p] && dead[q]) continue; /* both far below the pinv cut-off: left alone */
                 double apq = a[IX(p, q, m)];
+                if (JACOBI_LEFT_ALONE(p, q, apq)) continue;
                 double g = 100.0 * fabs(apq);
                 if (sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q])) {
                     a[IX(p, q, m)] = 0.0;
@@ -166,6 +173,7 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
 #undef ROT
                 }
             }
+#undef JACOBI_LEFT_ALONE
         for (int i = 0; i < m; i++) {
             b[i] = b[i] + z[i];
             d[i] = b[i];
