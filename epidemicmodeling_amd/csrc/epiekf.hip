@@ -353,10 +353,16 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 // recursion, so it is hoisted out of the sequential smoother loop: one lane per (chain, step) pair,
 // (T-1)*B independent items.  This is where ~80 % of the path's flops are (cyclic Jacobi on a 6 x 6),
 // and as a flat grid it load-balances over all 1024 SIMDs instead of B/64 long-lived waves.
+// One wavefront per workgroup: the Jacobi iteration count is data dependent, and with 256-thread workgroups a SIMD's
+// wave slot stays empty until all four waves of a workgroup have finished (measured 1.67 resident waves per SIMD instead
+// of 2; 64-thread workgroups: 7.25 -> 6.6 ms on the headline sweep, 128: 6.9 ms).
+#ifndef EPI_PINV_WG
+#define EPI_PINV_WG 64
+#endif
 template <int M>
-__global__ __launch_bounds__(256) void eks_pinv(const KArgs a)
+__global__ __launch_bounds__(EPI_PINV_WG) void eks_pinv(const KArgs a)
 {
-    // grid: x = 256-chain tiles of the chain range, y = step; a workgroup shares one step => uniform row bases
+    // grid: x = EPI_PINV_WG-chain tiles of the chain range, y = step; a workgroup shares one step => uniform row bases
     const int cl = blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= a.cn) return;
     const int B = a.B;
@@ -863,7 +869,7 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
     }
     if (!smooth) return e;
     if (GENERIC && ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
-        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + 255) / 256), (unsigned)(ka.T - 1)), dim3(256), 0, st, ka);
+        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + EPI_PINV_WG - 1) / EPI_PINV_WG), (unsigned)(ka.T - 1)), dim3(EPI_PINV_WG), 0, st, ka);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phase == 0 || phase == 2 || phase == 4) {
@@ -957,7 +963,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 if ((e = hipEventRecord(lp->ev[h], st)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(lp->stream, lp->ev[h], 0)) != hipSuccess) return e;
-                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((kc.cn + 255) / 256), (unsigned)(ka.T - 1)), dim3(256), 0, lp->stream, kc);
+                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((kc.cn + EPI_PINV_WG - 1) / EPI_PINV_WG), (unsigned)(ka.T - 1)), dim3(EPI_PINV_WG), 0, lp->stream, kc);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             }
             if ((e = hipEventRecord(lp->ev[2], lp->stream)) != hipSuccess) return e;
