@@ -522,6 +522,9 @@ EPI_DEV void mrdivide(const double (&Bm)[M * M], const double (&A)[M * M], doubl
 #pragma unroll
         for (int i = j + 1; i < M; i++) {
             const bool sw = (piv == i);
+            // the chains of a wave (one region, neighbouring cost weights) mostly agree on the pivot row: a candidate
+            // row that no lane picks costs one ballot instead of 4*M selects
+            if (__builtin_amdgcn_ballot_w64(sw) == 0ull) continue;
 #pragma unroll
             for (int c = 0; c < M; c++) {
                 // dgetf2 swaps only when the pivot is non-zero; dgetrs applies ipiv regardless
