@@ -373,9 +373,10 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
     bool capped = true;
     for (int sweep = 1; sweep <= kJacobiMaxSweeps; sweep++) {
         // sym_pinv discards every eigenpair below tol = M*eps(max|d|); an index is "dead" when its diagonal entry is
-        // below 2^-10 of that cut-off.  Left alone (not rotated, zeroed or counted in the convergence sum; same rule
-        // as the oracle): pairs of two dead indices, and dead/live pairs whose 100|a_pq| vanishes against the live
-        // diagonal entry.  X changes by <1e-18 relative, the rotations by -30 %.
+        // below 2^-10 of that cut-off.  Left alone for this sweep (not rotated, zeroed or counted in the convergence sum;
+        // same rule as the oracle): pairs of two dead indices, and dead/live pairs whose 100|a_pq| vanishes against the
+        // live diagonal entry -- both judged on the values at the start of the sweep.  X changes by <1e-18 relative,
+        // the rotations by -30 %, the pair tests by another -28 %.
         double dmax = 0.0;
 #pragma unroll
         for (int i = 0; i < M; i++) dmax = fmax(dmax, fabs(d[i]));
@@ -383,11 +384,15 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
         bool dead[M];
 #pragma unroll
         for (int i = 0; i < M; i++) dead[i] = fabs(d[i]) < cut;
+        bool la[M * M];
         double sm = 0.0;
 #pragma unroll
         for (int p = 0; p < M - 1; p++)
 #pragma unroll
-            for (int q = p + 1; q < M; q++) sm = jacobi_left_alone(dead[p], dead[q], d[p], d[q], a[IXM(p, q)]) ? sm : sm + fabs(a[IXM(p, q)]);
+            for (int q = p + 1; q < M; q++) {
+                la[IXM(p, q)] = jacobi_left_alone(dead[p], dead[q], d[p], d[q], a[IXM(p, q)]);
+                sm = la[IXM(p, q)] ? sm : sm + fabs(a[IXM(p, q)]);
+            }
         if (sm == 0.0) { capped = false; break; }
         const double tresh = (sweep < 4) ? 0.2 * sm / (double)(M * M) : 0.0;
 #pragma unroll
@@ -398,9 +403,10 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
                 // for a wavefront: the pair is skipped only if NO lane rotates it (wave-uniform branch, no exec-mask
                 // bookkeeping); inside, every lane applies a rotation, the identity (t = 0 => c = 1, s = tau = 0,
                 // which leaves every operand bit-wise unchanged) for the lanes that do not rotate.
+                if (__builtin_amdgcn_ballot_w64(!la[IXM(p, q)]) == 0ull) continue;   // in play in no lane this sweep
                 const double apq = a[IXM(p, q)];
                 const double g = 100.0 * fabs(apq);
-                const bool live = !jacobi_left_alone(dead[p], dead[q], d[p], d[q], apq);
+                const bool live = !la[IXM(p, q)];
                 const bool negl = live && sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q]);
                 const bool rot = live && !negl && (fabs(apq) > tresh);
                 if (__builtin_amdgcn_ballot_w64(rot) != 0ull) {

@@ -108,8 +108,8 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
     }
     for (int sweep = 1; sweep <= ORC_JACOBI_MAX_SWEEPS; sweep++) {
         /* The caller (orc_sym_pinv) discards every eigenpair below tol = m*eps(max|d|).  Call an index "dead" when
-         * its diagonal entry is below 2^-10 of that cut-off.  Two kinds of pairs are left alone (neither rotated,
-         * zeroed nor counted in the convergence sum):
+         * its diagonal entry is below 2^-10 of that cut-off.  Two kinds of pairs are left alone for the sweep (neither
+         * rotated, zeroed nor counted in the convergence sum), judged on the values at the START of the sweep:
          *   - both indices dead: the rotation only mixes directions that are discarded anyway;
          *   - one dead, one live, and 100|a_pq| vanishes against the live diagonal entry: the rotation angle is
          *     below eps/100, so the live eigenpair would not move; only the dead entry's relative accuracy is at
@@ -118,21 +118,22 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
         double dmax = 0.0;
         for (int i = 0; i < m; i++) dmax = fmax(dmax, fabs(d[i]));
         const double cut = ((double)m * eps_of(dmax)) * 0x1p-10;
-        int dead[MM];
+        int dead[MM], la[MM * MM];
         for (int i = 0; i < m; i++) dead[i] = skip_dead && (fabs(d[i]) < cut);
-#define JACOBI_LEFT_ALONE(p, q, apq)                                                                      \
-    ((dead[p] && dead[q]) ||                                                                              \
-     (dead[p] != dead[q] && (fabs(d[dead[p] ? (q) : (p)]) + 100.0 * fabs(apq)) == fabs(d[dead[p] ? (q) : (p)])))
         double sm = 0.0;
         for (int p = 0; p < m - 1; p++)
-            for (int q = p + 1; q < m; q++)
-                if (!JACOBI_LEFT_ALONE(p, q, a[IX(p, q, m)])) sm = sm + fabs(a[IX(p, q, m)]);
+            for (int q = p + 1; q < m; q++) {
+                const double apq = a[IX(p, q, m)];
+                const double dl = fabs(d[dead[p] ? q : p]); /* the live entry of a mixed pair */
+                la[IX(p, q, m)] = (dead[p] && dead[q]) || (dead[p] != dead[q] && (dl + 100.0 * fabs(apq)) == dl);
+                if (!la[IX(p, q, m)]) sm = sm + fabs(apq);
+            }
         if (sm == 0.0) break;
         double tresh = (sweep < 4) ? 0.2 * sm / (double)(m * m) : 0.0;
         for (int p = 0; p < m - 1; p++)
             for (int q = p + 1; q < m; q++) {
+                if (la[IX(p, q, m)]) continue;
                 double apq = a[IX(p, q, m)];
-                if (JACOBI_LEFT_ALONE(p, q, apq)) continue;
                 double g = 100.0 * fabs(apq);
                 if (sweep > 4 && (fabs(d[p]) + g) == fabs(d[p]) && (fabs(d[q]) + g) == fabs(d[q])) {
                     a[IX(p, q, m)] = 0.0;
@@ -173,7 +174,6 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
 #undef ROT
                 }
             }
-#undef JACOBI_LEFT_ALONE
         for (int i = 0; i < m; i++) {
             b[i] = b[i] + z[i];
             d[i] = b[i];
