@@ -86,6 +86,60 @@ struct ModelFlags {
 };
 
 EPI_DEV bool is_nan(double v) { return v != v; }
+
+// ---- exp and tanh with a fixed operation order -----------------------------------------------------------------
+// Rt_ExpFitEKF.m and SEIRPSaturatedResource.m call exp / tanh.  libm (CPU oracle) and the device math library round
+// them differently, and a nearly singular 2 x 2 smoother gain amplifies that last-bit difference (seen: 1e-9 on
+// P_SMOOTH).  Both sides therefore evaluate the SAME sequence: k = rint(x/ln2), two-part Cody-Waite reduction,
+// degree-13 Taylor polynomial of expm1 in Horner form with fma, exact scaling by 2^k.  Error < 1 ulp for exp, a few
+// ulp for tanh -- against MATLAB's own exp/tanh that is far inside the 1e-6 bar, and the parity tests become bit for
+// bit.  oracle/ekf_oracle.c holds the same text.
+EPI_DEV double epi_expm1_reduced(double r)
+{
+    // sum_{n>=2} r^(n-2)/n!, Horner with fma; the constants are correctly rounded quotients on every IEEE compiler
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    return fma(q * r, r, r);
+}
+EPI_DEV double epi_reduce_ln2(double y, double *k)
+{
+    *k = rint(y * 1.44269504088896338700e+00);
+    double r = fma(-*k, 6.93147180369123816490e-01, y);      // ln2 high part: 32 significant bits, k*hi exact
+    return fma(-*k, 1.90821492927058770002e-10, r);          // ln2 low part
+}
+EPI_DEV double epi_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.78271289338397) return (double)INFINITY;
+    if (x < -745.13321910194122) return 0.0;
+    double k;
+    const double r = epi_reduce_ln2(x, &k);
+    return ldexp(1.0 + epi_expm1_reduced(r), (int)k);
+}
+EPI_DEV double epi_tanh(double x)
+{
+    if (x != x) return x;
+    const double ax = fabs(x);
+    double res = 1.0;                                         // |x| > 22: 1 - 2e-19 rounds to 1
+    if (ax <= 22.0) {
+        double k;
+        const double r = epi_reduce_ln2(ax + ax, &k);
+        const double q = epi_expm1_reduced(r);                // e^(2|x|) = 2^k (1 + q)
+        const double s = ldexp(1.0, (int)k);                  // tanh = (e - 1)/(e + 1), both formed with one rounding
+        res = fma(s, q, s - 1.0) / fma(s, q, s + 1.0);
+    }
+    return copysign(res, x);
+}
 EPI_DEV bool is_nonfinite(double v) { return !(fabs(v) <= 1.7976931348623157e308); }
 
 template <int M>

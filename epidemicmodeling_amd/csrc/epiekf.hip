@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void seirp_sim(int B, int K, int par_steps, do
         r.rho = par[(pt * 7 + 3) * B + c]; r.beta = par[(pt * 7 + 4) * B + c]; r.mu = par[(pt * 7 + 5) * B + c];
         r.gamma = par[(pt * 7 + 6) * B + c];
         if (saturated) {   // SEIRPSaturatedResource.m:27-29
-            const double h = (tanh((y[2] - i_0) / sg) + 1.0) / 2.0;
+            const double h = (epi_tanh((y[2] - i_0) / sg) + 1.0) / 2.0;
             r.beta = (bs - b0) * h + b0;
             r.mu = (ms - m0) * h + m0;
         }

@@ -22,8 +22,8 @@ struct RtModel { double ts, alpha, sigma, w1, w2; };
 EPI_DEV void rt_jacobian(const RtModel &m, const double (&s)[2], double (&A)[4], double &E, double &tnh, double &omt)
 {
     constexpr int M = 2;
-    E = exp(m.ts * s[1]);
-    tnh = tanh((m.alpha * s[1] + m.w2) / m.sigma);
+    E = epi_exp(m.ts * s[1]);
+    tnh = epi_tanh((m.alpha * s[1] + m.w2) / m.sigma);
     omt = 1.0 - tnh * tnh;
     A[IXM(0, 0)] = E; A[IXM(0, 1)] = (m.ts * s[0]) * E; A[IXM(1, 0)] = 0.0; A[IXM(1, 1)] = m.alpha * omt;
 }

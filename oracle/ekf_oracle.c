@@ -87,6 +87,62 @@ static void symmetrize(int m, double *P) /* P = (P + P')/2.0 */
  * b/z accumulators), run on A scaled by an exact power of two.  The kept terms
  * are accumulated in the eigenvalue index order the iteration leaves them in;
  * only the upper triangle of X is accumulated and then mirrored. */
+/* ---- exp and tanh with a fixed operation order ----------------------------------------------------------------
+ * Rt_ExpFitEKF.m and SEIRPSaturatedResource.m call exp / tanh.  libm and the GPU's math library round them
+ * differently, and a nearly singular 2 x 2 smoother gain amplifies that last-bit difference (seen: 1e-9 on
+ * P_SMOOTH).  Oracle and kernels therefore evaluate the SAME sequence: k = rint(x/ln2), two-part Cody-Waite
+ * reduction, degree-13 Taylor polynomial of expm1 in Horner form with fma, exact scaling by 2^k.  Error < 1 ulp for
+ * exp, a few ulp for tanh (tests/test_oracle.py checks both against libm). */
+static double epi_expm1_reduced(double r)
+{
+    /* sum_{n>=2} r^(n-2)/n!, Horner with fma; the constants are correctly rounded quotients on every IEEE compiler */
+    double q = 1.0 / 6227020800.0;
+    q = fma(q, r, 1.0 / 479001600.0);
+    q = fma(q, r, 1.0 / 39916800.0);
+    q = fma(q, r, 1.0 / 3628800.0);
+    q = fma(q, r, 1.0 / 362880.0);
+    q = fma(q, r, 1.0 / 40320.0);
+    q = fma(q, r, 1.0 / 5040.0);
+    q = fma(q, r, 1.0 / 720.0);
+    q = fma(q, r, 1.0 / 120.0);
+    q = fma(q, r, 1.0 / 24.0);
+    q = fma(q, r, 1.0 / 6.0);
+    q = fma(q, r, 0.5);
+    return fma(q * r, r, r);
+}
+static double epi_reduce_ln2(double y, double *k)
+{
+    *k = rint(y * 1.44269504088896338700e+00);
+    double r = fma(-*k, 6.93147180369123816490e-01, y);      /* ln2 high part: 32 significant bits, k*hi exact */
+    return fma(-*k, 1.90821492927058770002e-10, r);          /* ln2 low part */
+}
+static double epi_exp(double x)
+{
+    if (x != x) return x;
+    if (x > 709.78271289338397) return (double)INFINITY;
+    if (x < -745.13321910194122) return 0.0;
+    double k;
+    const double r = epi_reduce_ln2(x, &k);
+    return ldexp(1.0 + epi_expm1_reduced(r), (int)k);
+}
+static double epi_tanh(double x)
+{
+    if (x != x) return x;
+    const double ax = fabs(x);
+    double res = 1.0;                                         /* |x| > 22: 1 - 2e-19 rounds to 1 */
+    if (ax <= 22.0) {
+        double k;
+        const double r = epi_reduce_ln2(ax + ax, &k);
+        const double q = epi_expm1_reduced(r);                /* e^(2|x|) = 2^k (1 + q) */
+        const double s = ldexp(1.0, (int)k);                  /* tanh = (e - 1)/(e + 1), both formed with one rounding */
+        res = fma(s, q, s - 1.0) / fma(s, q, s + 1.0);
+    }
+    return copysign(res, x);
+}
+
+double orc_exp(double x) { return epi_exp(x); }
+double orc_tanh(double x) { return epi_tanh(x); }
+
 static double eps_of(double x) /* MATLAB eps(x) for finite x >= 0 */
 {
     if (x == 0.0) return 4.9406564584124654e-324;
@@ -803,7 +859,7 @@ void orc_seirp_saturated(const double *alpha_e, const double *alpha_i, const dou
 {
     s[0] = s0; e[0] = e0; i[0] = i0; r[0] = r0; p[0] = p0;
     for (int t = 0; t < K - 1; t++) { /* SEIRPSaturatedResource.m:26-36 */
-        double h = (tanh((i[t] - i_0) / sigma) + 1.0) / 2.0;
+        double h = (epi_tanh((i[t] - i_0) / sigma) + 1.0) / 2.0;
         double beta = (beta_s - beta_0) * h + beta_0;
         double mu = (mu_s - mu_0) * h + mu_0;
         s[t + 1] = (-alpha_e[t] * s[t] * e[t] - alpha_i[t] * s[t] * i[t] + gamma[t] * r[t]) * dt + s[t];
@@ -1048,8 +1104,8 @@ int orc_rt_expfit_ekf(int T, const double *x, const double *s_init, const double
             memcpy(Pp, Pm, sizeof Pp); memcpy(sp, sm, sizeof sp);
         }
         /* NlinStateUpdate :133-140, StateJacobians :148-160 */
-        const double E = exp(ts * sp[1]);
-        const double tnh = tanh((alpha * sp[1] + w_bar[1]) / sigma);
+        const double E = epi_exp(ts * sp[1]);
+        const double tnh = epi_tanh((alpha * sp[1] + w_bar[1]) / sigma);
         const double omt = 1 - tnh * tnh;
         double fs[2] = {0, 0}, fw[2] = {0, 0}, Fsp[4] = {0, 0, 0, 0}, Fwp[4] = {0, 0, 0, 0};
         if (order == 2) {                                       /* StateHessianTerms :163-199 */
@@ -1100,8 +1156,8 @@ int orc_rt_expfit_ekf(int T, const double *x, const double *s_init, const double
         for (int k = T - 2; k >= 0; k--) {
             const double *sp = S_PLUS + 2 * (size_t)k, *Pp = P_PLUS + 4 * (size_t)k;
             const double *Sm1 = S_MINUS + 2 * (size_t)(k + 1), *Pm1 = P_MINUS + 4 * (size_t)(k + 1);
-            const double E = exp(ts * sp[1]);
-            const double tnh = tanh((alpha * sp[1] + w_bar[1]) / sigma);
+            const double E = epi_exp(ts * sp[1]);
+            const double tnh = epi_tanh((alpha * sp[1] + w_bar[1]) / sigma);
             double A[4], T1[4], J[4], D[4], T2[4];
             A[IX(0, 0, 2)] = E; A[IX(0, 1, 2)] = (ts * sp[0]) * E; A[IX(1, 0, 2)] = 0; A[IX(1, 1, 2)] = alpha * (1 - tnh * tnh);
             mat_mul_bt(2, Pp, A, T1);

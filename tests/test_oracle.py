@@ -339,6 +339,32 @@ def _rt_args(w, c):
             rp[15:19].reshape(2, 2, order="F"), rp[6], rp[7], rp[8], w.L, w.order)
 
 
+def test_fixed_order_exp_and_tanh_track_libm():
+    """epi_exp / epi_tanh (the fixed operation order shared by the oracle and the kernels) against libm: exp within 1 ulp
+    over the whole finite range, tanh within 4 ulp; special values and saturation."""
+    import ctypes as C
+    import math
+    lib = olib.lib()
+    lib.orc_exp.restype = C.c_double; lib.orc_exp.argtypes = [C.c_double]
+    lib.orc_tanh.restype = C.c_double; lib.orc_tanh.argtypes = [C.c_double]
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-745, 709.7, 4000), rng.uniform(-2, 2, 4000), rng.normal(0, 1e-3, 500),
+                         [0.0, -0.0, 1.0, -1.0, 709.78, -745.0, -708.4, 1e-300, -1e-300, 0.34657359027997264]])
+    for x in xs:
+        e, r = lib.orc_exp(float(x)), math.exp(float(x))
+        assert abs(e - r) <= np.spacing(r), (x, e, r)
+    assert lib.orc_exp(710.0) == math.inf and lib.orc_exp(-746.0) == 0.0 and math.isnan(lib.orc_exp(math.nan))
+    assert lib.orc_exp(-math.inf) == 0.0 and lib.orc_exp(math.inf) == math.inf and lib.orc_exp(0.0) == 1.0
+    ts = np.concatenate([rng.uniform(-25, 25, 4000), rng.uniform(-0.5, 0.5, 4000), rng.normal(0, 1e-6, 500),
+                         [0.0, 1e-320, 0.17328679513998632, 22.0, 22.000001, 1e6]])
+    for x in ts:
+        t, r = lib.orc_tanh(float(x)), math.tanh(float(x))
+        assert abs(t - r) <= 4 * np.spacing(abs(r)), (x, t, r)
+        assert lib.orc_tanh(-float(x)) == -t
+    assert math.copysign(1.0, lib.orc_tanh(-0.0)) == -1.0 and math.isnan(lib.orc_tanh(math.nan))
+    assert lib.orc_tanh(math.inf) == 1.0 and lib.orc_tanh(-math.inf) == -1.0
+
+
 @pytest.mark.parametrize("order", [1, 2])
 def test_rt_expfit_c_oracle_matches_numpy_restatement(order):
     """Two independent readings of Tools/Rt_ExpFitEKF.m (C, fma-ordered; NumPy/LAPACK) agree to rounding level,
@@ -466,13 +492,13 @@ def _aux(name):
 
 def test_oracle_reproduces_aux_golden_vectors():
     """Committed fixtures (tests/golden/make_golden_aux.py) pin the oracle's Rt_ExpFitEKF, preprocessing, NNLS, plans and
-    Pareto filter: integer / selection outputs bit for bit; floating-point outputs bit for bit too on this toolchain,
-    with a 1e-12 allowance for libm's exp/tanh in Rt_ExpFitEKF should the host's libm differ."""
+    Pareto filter: integer / selection outputs bit for bit; floating-point outputs bit for bit too (exp/tanh in
+    Rt_ExpFitEKF are the oracle's own fixed-order epi_exp/epi_tanh, not libm)."""
     for order in (1, 2):
         g = _aux(f"aux_rt_order{order}")
         ob = olib.rt_expfit_batch(g["in_x"], g["in_rp"], int(g["in_L"]), order)
         for k, v in ob.items():
-            assert H.rel_err(v, g["out_" + k]) <= 1e-12, (order, k)
+            assert np.array_equal(v, g["out_" + k], equal_nan=True), (order, k)
     g = _aux("aux_preprocess")
     for r in range(g["in_cases"].shape[1]):
         o = olib.preprocess_region(g["in_cases"][:, r], g["in_deaths"][:, r], g["in_population"][r])
