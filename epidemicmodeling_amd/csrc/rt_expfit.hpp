@@ -4,8 +4,8 @@
 // Same execution shape as the SI-alpha kernels: one lane per chain, arrays [T][rows][B] chain-minor, the three
 // innovation windows as LDS ring buffers.  State and covariance are 2 + 4 doubles, so the kernels are bound by
 // their stores (fwd 128 B/step) and loads (bwd 96 B/step); occupancy is limited by the LDS windows only.
-// exp / tanh are the device math library's: parity with the CPU oracle (libm) is tolerance-based for this
-// function, not bit-exact.
+// exp / tanh are epi_exp / epi_tanh (ekf_device.hpp; the oracle evaluates the same sequence), so parity with the CPU
+// oracle is bit for bit here too.
 #pragma once
 
 struct RtArgs {

@@ -253,8 +253,8 @@ int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double
  * rp [EPI_RT_PRM_COUNT][B] holding every other argument of the signature per chain.  Outputs [T][2][B] (S_*, K_GAIN),
  * [T][4][B] (P_*, column-major 2 x 2), [T][B] (innovations, rho).  S_MINUS, S_PLUS, P_MINUS, P_PLUS are required
  * (the smoother reads them back); the others may be NULL.  `order` other than 1 or 2 returns
- * EPI_ERR_UNDEFINED_ORDER ('Undefined order', Rt_ExpFitEKF.m:46,77).  exp/tanh come from the device math library:
- * results agree with a libm evaluation to rounding level, not bit for bit. */
+ * EPI_ERR_UNDEFINED_ORDER ('Undefined order', Rt_ExpFitEKF.m:46,77).  exp/tanh are evaluated in a fixed operation
+ * order (< 1 ulp / a few ulp from libm) that the CPU oracle shares: results are reproducible bit for bit. */
 enum {
     EPI_RT_TIME_SCALE = 0, EPI_RT_ALPHA = 1, EPI_RT_SIGMA = 2,   /* params(1:3) */
     EPI_RT_W_BAR = 3,      /* w_bar(1:2) */

@@ -1042,8 +1042,8 @@ void orc_pareto_front(int P, const double *J0, const double *J1, int *on_front, 
 
 /* ------------------------------------------------------------------------------------------------
  * Tools/Rt_ExpFitEKF.m:1-227 -- 2-state exponential-fit EKF/EKS with second-order (Hessian) terms
- * (SURVEY.md 8(f3)).  exp / tanh are libm's; the HIP kernels use the device math library, so parity
- * for this function is tolerance-based (stated in the tests), not bit-exact.
+ * (SURVEY.md 8(f3)).  exp / tanh are epi_exp / epi_tanh above (the fixed operation order the HIP kernels use
+ * too), so parity for this function is bit for bit like the other filters.
  * ---------------------------------------------------------------------------------------------- */
 static double trace2(const double *M) { return M[0] + M[3]; }
 
