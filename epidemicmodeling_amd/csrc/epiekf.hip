@@ -353,16 +353,17 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 // recursion, so it is hoisted out of the sequential smoother loop: one lane per (chain, step) pair,
 // (T-1)*B independent items.  This is where ~80 % of the path's flops are (cyclic Jacobi on a 6 x 6),
 // and as a flat grid it load-balances over all 1024 SIMDs instead of B/64 long-lived waves.
-// One wavefront per workgroup: the Jacobi iteration count is data dependent, and with 256-thread workgroups a SIMD's
-// wave slot stays empty until all four waves of a workgroup have finished (measured 1.67 resident waves per SIMD instead
-// of 2; 64-thread workgroups: 7.25 -> 6.6 ms on the headline sweep, 128: 6.9 ms).
-#ifndef EPI_PINV_WG
-#define EPI_PINV_WG 64
-#endif
+// 6 x 6: one wavefront per workgroup.  The Jacobi iteration count is data dependent, and with 256-thread workgroups a
+// SIMD's wave slot stays empty until all four waves of a workgroup have finished (measured 1.67 resident waves per SIMD
+// instead of 1.9; 7.25 -> 6.6 ms on the headline sweep, 128 threads: 6.9 ms).  3 x 3: the waves are short and nearly
+// uniform, and four times as many workgroups cost more than the slots they free (5.2 -> 5.9 ms on the 307 200-chain
+// ensemble), so they keep 256 threads.
 template <int M>
-__global__ __launch_bounds__(EPI_PINV_WG) void eks_pinv(const KArgs a)
+constexpr int pinv_wg() { return M >= 6 ? 64 : 256; }
+template <int M>
+__global__ __launch_bounds__(pinv_wg<M>()) void eks_pinv(const KArgs a)
 {
-    // grid: x = EPI_PINV_WG-chain tiles of the chain range, y = step; a workgroup shares one step => uniform row bases
+    // grid: x = pinv_wg<M>()-chain tiles of the chain range, y = step; a workgroup shares one step => uniform row bases
     const int cl = blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= a.cn) return;
     const int B = a.B;
@@ -869,7 +870,7 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
     }
     if (!smooth) return e;
     if (GENERIC && ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
-        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + EPI_PINV_WG - 1) / EPI_PINV_WG), (unsigned)(ka.T - 1)), dim3(EPI_PINV_WG), 0, st, ka);
+        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, st, ka);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (phase == 0 || phase == 2 || phase == 4) {
@@ -963,7 +964,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 if ((e = hipEventRecord(lp->ev[h], st)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(lp->stream, lp->ev[h], 0)) != hipSuccess) return e;
-                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((kc.cn + EPI_PINV_WG - 1) / EPI_PINV_WG), (unsigned)(ka.T - 1)), dim3(EPI_PINV_WG), 0, lp->stream, kc);
+                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((kc.cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, lp->stream, kc);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             }
             if ((e = hipEventRecord(lp->ev[2], lp->stream)) != hipSuccess) return e;

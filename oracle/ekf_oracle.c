@@ -249,7 +249,7 @@ int orc_sym_pinv(int m, const double *A, double *X)
     /* only the upper triangle (i<=j) is referenced, as the iteration does */
     for (int j = 0; j < m; j++)
         for (int i = 0; i < m; i++) a[IX(i, j, m)] = ldexp(A[IX(i <= j ? i : j, i <= j ? j : i, m)], -e);
-    jacobi_eig(m, a, d, v, 1); /* the eigenpairs below tol are discarded right below */
+    jacobi_eig(m, a, d, v, m > 3); /* the eigenpairs below tol are discarded right below; 3 x 3: plain iteration */
     double smax = 0.0;
     for (int i = 0; i < m; i++) smax = fmax(smax, fabs(d[i]));
     double tol = (double)m * eps_of(smax);
