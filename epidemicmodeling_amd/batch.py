@@ -266,6 +266,26 @@ def pareto_front(J0, J1, n_regions):
     return on.bool(), io
 
 
+def npi_cost(newcases, inputs, weights, u_series=None, device="cuda:0"):
+    """Batched Tools/NPICost.m: newcases [T, B], inputs [T, n_npi, Su], weights [T, n_npi, B] or [n_npi, B] (the same
+    every day).  Returns (J0, J1) torch [B]."""
+    dev = torch.device(device)
+    t = lambda a, dt=torch.float64: None if a is None else (a.contiguous() if isinstance(a, torch.Tensor) else
+                                                            torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(dev))
+    nc, u, w, us = t(newcases), t(inputs), t(weights), t(u_series, torch.int32)
+    T, B = nc.shape
+    n_npi, Su = u.shape[1], u.shape[2]
+    if u.shape[0] != T or w.shape[-1] != B or w.shape[-2] != n_npi or (w.dim() == 3 and w.shape[0] != T):
+        raise ValueError("NPICost: newcases, inputs and weights do not agree in size")
+    J0 = torch.empty((B,), dtype=torch.float64, device=dev); J1 = torch.empty_like(J0)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_npi_cost_device(B, T, n_npi, Su, int(w.dim() == 3), _ptr(us), _ptr(nc), _ptr(u), _ptr(w), _ptr(J0),
+                                        _ptr(J1), C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return J0, J1
+
+
 def preprocess(cases, population, deaths=None, ip=None, W=7, min_cases=1.0, first_num_days=7, outputs=None,
                device="cuda:0"):
     """Per-region preprocessing on the device (Tools/TrainPredictPrescribeNPI.m:142-198,201-202,240).

@@ -1311,6 +1311,20 @@ int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double
     return EPI_OK;
 }
 
+int epi_npi_cost_device(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t weights_per_day,
+                        const int32_t *u_series, const double *newcases, const double *inputs, const double *weights,
+                        double *J0, double *J1, void *stream, char *err)
+{
+    if (B < 1 || T < 1 || n_npi < 1 || Su < 1 || !newcases || !inputs || !weights || !J0 || !J1 || (!u_series && Su != B)) {
+        set_err(err, "bad NPICost arguments"); return EPI_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(npi_cost, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, T, n_npi, Su,
+                       weights_per_day, u_series, newcases, inputs, weights, J0, J1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "npi_cost launch");
+    return EPI_OK;
+}
+
 int epi_rt_expfit_validate(const epi_rt_desc *d, char *err)
 {
     if (!d) { set_err(err, "NULL descriptor"); return EPI_ERR_BAD_ARG; }

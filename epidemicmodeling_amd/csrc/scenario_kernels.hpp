@@ -141,3 +141,26 @@ __global__ __launch_bounds__(256) void pareto_front(int P, const double *__restr
     }
     if (tid == 0 && i_opt) i_opt[r] = is_nan(red_a[0]) ? 0 : red_i[0];   // min of all-NaN returns index 1
 }
+
+// Tools/NPICost.m:1-10, one lane per chain: both means as sequential sums in column-major element order
+__global__ __launch_bounds__(256) void npi_cost(int B, int T, int n_npi, int Su, int per_day, const int32_t *__restrict__ u_series,
+                                                const double *__restrict__ newcases, const double *__restrict__ inputs,
+                                                const double *__restrict__ weights, double *__restrict__ J0,
+                                                double *__restrict__ J1)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    const int su = u_series ? u_series[c] : c;
+    double a0 = 0.0, a1 = 0.0;
+    for (int t = 0; t < T; t++) {
+        const double nc = newcases[(size_t)t * B + c];
+        a0 = (t == 0) ? nc : a0 + nc;                                                  // :6
+        for (int k = 0; k < n_npi; k++) {
+            const double w = weights[((size_t)(per_day ? t : 0) * n_npi + k) * B + c];
+            const double term = w * inputs[((size_t)t * n_npi + k) * Su + su];         // :9
+            a1 = (t == 0 && k == 0) ? term : a1 + term;                                // :10
+        }
+    }
+    J0[c] = a0 / (double)T;
+    J1[c] = a1 / (double)((size_t)n_npi * (size_t)T);
+}

@@ -272,3 +272,117 @@ def Rt_ExpFitEKF(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma
     return (S("S_MINUS"), S("S_PLUS"), P("P_MINUS"), P("P_PLUS"), np.asfortranarray(out["K_GAIN"][:, :, 0].T.reshape(2, 1, T)),
             S("S_SMOOTH"), P("P_SMOOTH"), out["innovations"][:, 0, 0].reshape(1, T).copy(),
             out["rho"][:, 0, 0].reshape(T, 1).copy())          # squeeze(rho): T x 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# forward simulators and the NPI cost: one call = one chain through the batched device entry
+# points (epi_sialpha_sim_device, epi_seirp_sim_device, epi_npi_cost_device)
+# ---------------------------------------------------------------------------------------------------------------------
+def _matlab_round(v):
+    """MATLAB round(): halves away from zero."""
+    return int(np.floor(abs(v) + 0.5) * (1 if v >= 0 else -1))
+
+
+def _per_step(name, v, need):
+    """A per-step parameter array indexed (1 : need) by the .m loop: shorter => MATLAB's index error."""
+    a = np.asarray(v, dtype=np.float64).reshape(-1)
+    if a.shape[0] < need:
+        raise IndexError(f"Index exceeds the number of array elements ({name}).")
+    return a
+
+
+def SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a, b, beta, s_noise_std, i_noise_std,
+                       alpha_noise_std, K, dt, noise=None, rng=None, device="cuda:0"):
+    """[s, i, alpha] = SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a, b, beta,
+    s_noise_std, i_noise_std, alpha_noise_std, K, dt) -- Tools/SIalpha_Controlled.m:1 (forward Euler, clamps, the
+    initial sample dropped :30-32).  u is n_npi x K.  The .m draws three randn per step from MATLAB's global stream,
+    which cannot be reproduced outside MATLAB: pass `noise` (3 x K standard-normal draws, rows = s, i, alpha) for a
+    reproducible run; otherwise they come from `rng` (numpy Generator, default: a fresh one) when any noise std is
+    non-zero.  Returns three 1 x K arrays."""
+    from . import batch
+    K = int(K)
+    u = np.asarray(u, dtype=np.float64)
+    if u.ndim != 2 or u.shape[1] < K:
+        raise IndexError("Index in position 2 exceeds array bounds (u).")                  # u(:, t), :27
+    n = u.shape[0]
+    a = np.asarray(a, dtype=np.float64).reshape(-1); u_max = np.asarray(u_max, dtype=np.float64).reshape(-1)
+    if a.shape[0] != n or u_max.shape[0] != n:
+        raise ValueError("Incorrect dimensions for matrix multiplication (a'*(u_max - u(:, t))).")
+    if n > 12:
+        raise ValueError("this engine supports at most 12 NPIs")
+    sp = np.zeros((batch.SIM_PRM_COUNT, 1))
+    for name, v in (("s0", s0), ("i0", i0), ("alpha0", alpha0), ("alpha_min", alpha_min), ("alpha_max", alpha_max),
+                    ("gamma", gamma), ("b", b), ("beta", beta), ("s_noise_std", s_noise_std), ("i_noise_std", i_noise_std),
+                    ("alpha_noise_std", alpha_noise_std), ("dt", dt)):
+        sp[batch.SIM_FIELDS[name], 0] = float(v)
+    sp[batch.SIM_A:batch.SIM_A + n, 0] = a
+    sp[batch.SIM_U_MAX:batch.SIM_U_MAX + n, 0] = u_max
+    z = None
+    if noise is not None:
+        z = np.asarray(noise, dtype=np.float64)
+        if z.shape != (3, K):
+            raise ValueError("noise must be 3 x K")
+    elif float(s_noise_std) != 0.0 or float(i_noise_std) != 0.0 or float(alpha_noise_std) != 0.0:
+        z = (rng or np.random.default_rng()).standard_normal((3, K))
+    zz = None if z is None else np.ascontiguousarray(z.T.reshape(K, 3, 1))
+    out = batch.sialpha_sim(np.ascontiguousarray(u[:, :K].T.reshape(K, n, 1)), sp, z=zz, device=device)
+    return tuple(out[k].cpu().numpy().reshape(1, K) for k in ("s", "i", "alpha"))
+
+
+def _seirp(per_step, init, T, dt, sat, device):
+    from . import batch
+    K = _matlab_round(float(T) / float(dt))
+    if K < 1:
+        raise IndexError("Index exceeds the number of array elements (s(1) = s0 with K = 0).")
+    par = np.zeros((K, 7, 1))
+    for j, (name, v) in enumerate(per_step):
+        if v is None:
+            continue
+        a = _per_step(name, v, K - 1)
+        par[:min(K, a.shape[0]), j, 0] = a[:K]
+    out = batch.seirp_sim(par, np.asarray(init, dtype=np.float64).reshape(5, 1), float(dt), K,
+                          sat=None if sat is None else np.asarray(sat, dtype=np.float64).reshape(6, 1), device=device)
+    o = out.cpu().numpy()
+    return tuple(o[:, q, 0].reshape(1, K) for q in range(5))
+
+
+def SEIRP(alpha_e, alpha_i, kappa, rho, beta, mu, gamma, s0, e0, i0, r0, p0, T, dt, device="cuda:0"):
+    """[s, e, i, r, p] = SEIRP(alpha_e, alpha_i, kappa, rho, beta, mu, gamma, s0, e0, i0, r0, p0, T, dt)
+    -- Tools/SEIRP.m:1 (forward Euler; K = round(T/dt) samples, the first one is the initial condition; the seven
+    parameters are per-step arrays of at least K-1 elements)."""
+    return _seirp((("alpha_e", alpha_e), ("alpha_i", alpha_i), ("kappa", kappa), ("rho", rho), ("beta", beta), ("mu", mu),
+                   ("gamma", gamma)), (s0, e0, i0, r0, p0), T, dt, None, device)
+
+
+def SEIRPSaturatedResource(alpha_e, alpha_i, kappa, rho, gamma, s0, e0, i0, r0, p0, T, dt, beta_0, beta_s, mu_0, mu_s,
+                           sigma, i_0, device="cuda:0"):
+    """[s, e, i, r, p] = SEIRPSaturatedResource(alpha_e, alpha_i, kappa, rho, gamma, s0, e0, i0, r0, p0, T, dt, beta_0,
+    beta_s, mu_0, mu_s, sigma, i_0) -- Tools/SEIRPSaturatedResource.m:1 (recovery and death rates gated by
+    tanh((i - i_0)/sigma), :27-29)."""
+    return _seirp((("alpha_e", alpha_e), ("alpha_i", alpha_i), ("kappa", kappa), ("rho", rho), ("beta", None), ("mu", None),
+                   ("gamma", gamma)), (s0, e0, i0, r0, p0), T, dt, (beta_0, beta_s, mu_0, mu_s, sigma, i_0), device)
+
+
+def NPICost(newcases, inputs, weights, device="cuda:0"):
+    """[J0, J1] = NPICost(newcases, inputs, weights) -- Tools/NPICost.m:1: J0 = mean(newcases),
+    J1 = mean(weights(:).*inputs(:)).  inputs and weights are n_npi x T (weights may also be n_npi x 1: implicit
+    expansion of `weights .* inputs`)."""
+    from . import batch
+    nc = np.asarray(newcases, dtype=np.float64).reshape(-1)
+    u = np.asarray(inputs, dtype=np.float64); w = np.asarray(weights, dtype=np.float64)
+    if u.ndim != 2:
+        raise ValueError("inputs must be n_npi x T")
+    n, T = u.shape
+    if w.ndim == 1:
+        w = w.reshape(-1, 1)
+    if w.shape not in ((n, T), (n, 1)):
+        raise ValueError("Arrays have incompatible sizes for this operation (weights .* inputs).")
+    if nc.shape[0] == T:
+        wd = np.ascontiguousarray(w.T.reshape(T, n, 1)) if w.shape[1] == T and T > 1 else np.ascontiguousarray(w[:, :1].reshape(n, 1))
+        J0, J1 = batch.npi_cost(nc.reshape(T, 1), np.ascontiguousarray(u.T.reshape(T, n, 1)), wd, device=device)
+        return float(J0.cpu()[0]), float(J1.cpu()[0])
+    # newcases and inputs of different lengths are legal in the .m (two independent means): two calls
+    J0, _ = batch.npi_cost(nc.reshape(-1, 1), np.zeros((nc.shape[0], 1, 1)), np.zeros((1, 1)), device=device)
+    wd = np.ascontiguousarray(w.T.reshape(T, n, 1)) if w.shape[1] == T and T > 1 else np.ascontiguousarray(w[:, :1].reshape(n, 1))
+    _, J1 = batch.npi_cost(np.zeros((T, 1)), np.ascontiguousarray(u.T.reshape(T, n, 1)), wd, device=device)
+    return float(J0.cpu()[0]), float(J1.cpu()[0])

@@ -215,6 +215,15 @@ int epi_sialpha_score_device(const epi_sim_desc *d, const int32_t *u_series, con
                              const double *z, const double *J0_prefix, const double *J1_prefix, double *s, double *i,
                              double *alpha, double *J0, double *J1, void *stream, char *err);
 
+/* Tools/NPICost.m:1-10 batched over B chains: J0 = mean(newcases), J1 = mean(weights(:).*inputs(:)), both summed
+ * sequentially in MATLAB's column-major element order (NPI index fastest, then time).  newcases [T][B];
+ * inputs [T][n_npi][Su] with u_series [B] or NULL (identity, Su == B); weights [T][n_npi][B] when
+ * weights_per_day != 0, else [n_npi][B] (the same weights every day, as TrainPredictPrescribeNPI.m:485-493 builds
+ * them).  J0, J1 [B]. */
+int epi_npi_cost_device(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t weights_per_day,
+                        const int32_t *u_series, const double *newcases, const double *inputs, const double *weights,
+                        double *J0, double *J1, void *stream, char *err);
+
 /* Random-NPI Monte-Carlo scenarios of a region (Tools/TrainPredictPrescribeNPI.m:496-521): n_scen plans on the K
  * forecast days with u(jj,t) = randi([NPI_MINS(jj), NPI_MAXES(jj)]) -- scenarios with 1-based index < n_scen/2 are
  * constant over time (:502), the rest are redrawn every day -- each simulated with SIalpha_Controlled from the
