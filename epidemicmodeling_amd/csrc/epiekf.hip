@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <tuple>
 #include <vector>
 #include "ekf_device.hpp"
 
@@ -1323,6 +1324,92 @@ int epi_npi_cost_device(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(err, e, "npi_cost launch");
     return EPI_OK;
+}
+
+// ---- host-pointer variants of the simulators and the cost (what a MEX gateway binds: matlab/epiekf_sim_mex.cpp) ----
+namespace {
+struct HostStage {   // device copies of host arrays for one call; frees everything on destruction
+    std::vector<void *> allocs;
+    std::vector<std::tuple<void *, void *, size_t>> downloads;
+    hipError_t e = hipSuccess;
+    ~HostStage() { for (void *p : allocs) (void)hipFree(p); }
+    void *in(const void *host, size_t bytes)
+    {
+        if (!host || e != hipSuccess) return nullptr;
+        void *p = nullptr;
+        if ((e = hipMalloc(&p, bytes)) != hipSuccess) return nullptr;
+        allocs.push_back(p);
+        e = hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
+        return p;
+    }
+    void *out(void *host, size_t bytes)
+    {
+        if (!host || e != hipSuccess) return nullptr;
+        void *p = nullptr;
+        if ((e = hipMalloc(&p, bytes)) != hipSuccess) return nullptr;
+        allocs.push_back(p);
+        downloads.emplace_back(host, p, bytes);
+        return p;
+    }
+    int finish(int rc, char *err)
+    {
+        if (rc != EPI_OK) return rc;
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        for (auto &d : downloads)
+            if (e == hipSuccess) e = hipMemcpy(std::get<0>(d), std::get<1>(d), std::get<2>(d), hipMemcpyDeviceToHost);
+        return e == hipSuccess ? EPI_OK : hip_fail(err, e, "host staging");
+    }
+};
+}  // namespace
+
+int epi_sialpha_sim_host(const epi_sim_desc *d, const int32_t *u_series, const double *u, const double *sp,
+                         const double *z, double *s, double *i, double *alpha, double *J0, double *J1, int device,
+                         char *err)
+{
+    if (!d || d->B < 1 || d->K < 1 || d->Su < 1 || d->n_npi < 1 || !u || !sp) { set_err(err, "bad simulator descriptor"); return EPI_ERR_BAD_ARG; }
+    if (d->u_block != 0) { set_err(err, "u_block is a device-side layout"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    const size_t B = d->B, K = d->K;
+    HostStage h;
+    const void *dus = h.in(u_series, B * 4), *du = h.in(u, K * d->n_npi * (size_t)d->Su * 8);
+    const void *dsp = h.in(sp, (size_t)EPI_SIM_PRM_COUNT * B * 8), *dz = h.in(z, K * 3 * B * 8);
+    void *ds = h.out(s, K * B * 8), *di = h.out(i, K * B * 8), *da = h.out(alpha, K * B * 8);
+    void *d0 = h.out(J0, B * 8), *d1 = h.out(J1, B * 8);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_sialpha_sim_device(d, (const int32_t *)dus, (const double *)du, (const double *)dsp, (const double *)dz,
+                                           (double *)ds, (double *)di, (double *)da, (double *)d0, (double *)d1, nullptr, err), err);
+}
+
+int epi_seirp_sim_host(int32_t B, int32_t K, int32_t par_steps, double dt, int32_t saturated, int32_t integrator,
+                       const double *par, const double *init, const double *sat, double *out, int device, char *err)
+{
+    if (B < 1 || K < 1 || par_steps < 1 || !par || !init || !out) { set_err(err, "bad SEIRP arguments"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    HostStage h;
+    const void *dp = h.in(par, (size_t)par_steps * 7 * B * 8), *di = h.in(init, (size_t)5 * B * 8), *ds = h.in(sat, (size_t)6 * B * 8);
+    void *dout = h.out(out, (size_t)K * 5 * B * 8);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_seirp_sim_device(B, K, par_steps, dt, saturated, integrator, (const double *)dp, (const double *)di,
+                                         (const double *)ds, (double *)dout, nullptr, err), err);
+}
+
+int epi_npi_cost_host(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t weights_per_day, const int32_t *u_series,
+                      const double *newcases, const double *inputs, const double *weights, double *J0, double *J1,
+                      int device, char *err)
+{
+    if (B < 1 || T < 1 || n_npi < 1 || Su < 1) { set_err(err, "bad NPICost arguments"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    HostStage h;
+    const void *dus = h.in(u_series, (size_t)B * 4), *dn = h.in(newcases, (size_t)T * B * 8);
+    const void *du = h.in(inputs, (size_t)T * n_npi * Su * 8);
+    const void *dw = h.in(weights, (size_t)(weights_per_day ? T : 1) * n_npi * B * 8);
+    void *d0 = h.out(J0, (size_t)B * 8), *d1 = h.out(J1, (size_t)B * 8);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_npi_cost_device(B, T, n_npi, Su, weights_per_day, (const int32_t *)dus, (const double *)dn,
+                                        (const double *)du, (const double *)dw, (double *)d0, (double *)d1, nullptr, err), err);
 }
 
 int epi_rt_expfit_validate(const epi_rt_desc *d, char *err)

@@ -275,9 +275,30 @@ def Rt_ExpFitEKF(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# forward simulators and the NPI cost: one call = one chain through the batched device entry
-# points (epi_sialpha_sim_device, epi_seirp_sim_device, epi_npi_cost_device)
+# forward simulators and the NPI cost: one call = one chain through the host-pointer entry
+# points epi_sialpha_sim_host, epi_seirp_sim_host, epi_npi_cost_host (what matlab/epiekf_sim_mex.cpp binds too)
 # ---------------------------------------------------------------------------------------------------------------------
+_SIM_FIELDS = {"s0": 0, "i0": 1, "alpha0": 2, "alpha_min": 3, "alpha_max": 4, "gamma": 5, "b": 6, "beta": 7,
+               "s_noise_std": 8, "i_noise_std": 9, "alpha_noise_std": 10, "dt": 11}
+_SIM_A, _SIM_U_MAX, _SIM_PRM_COUNT = 12, 24, 48
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data
+
+
+def _dev_index(device):
+    """0, "cuda:0" or a torch.device -> the HIP device ordinal."""
+    if isinstance(device, int):
+        return device
+    if not isinstance(device, str):
+        idx = getattr(device, "index", None)          # torch.device
+        if isinstance(idx, int):
+            return idx
+    t = str(device)
+    return int(t.rsplit(":", 1)[1]) if ":" in t else 0
+
+
 def _matlab_round(v):
     """MATLAB round(): halves away from zero."""
     return int(np.floor(abs(v) + 0.5) * (1 if v >= 0 else -1))
@@ -292,14 +313,13 @@ def _per_step(name, v, need):
 
 
 def SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a, b, beta, s_noise_std, i_noise_std,
-                       alpha_noise_std, K, dt, noise=None, rng=None, device="cuda:0"):
+                       alpha_noise_std, K, dt, noise=None, rng=None, device=0):
     """[s, i, alpha] = SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a, b, beta,
     s_noise_std, i_noise_std, alpha_noise_std, K, dt) -- Tools/SIalpha_Controlled.m:1 (forward Euler, clamps, the
     initial sample dropped :30-32).  u is n_npi x K.  The .m draws three randn per step from MATLAB's global stream,
     which cannot be reproduced outside MATLAB: pass `noise` (3 x K standard-normal draws, rows = s, i, alpha) for a
     reproducible run; otherwise they come from `rng` (numpy Generator, default: a fresh one) when any noise std is
     non-zero.  Returns three 1 x K arrays."""
-    from . import batch
     K = int(K)
     u = np.asarray(u, dtype=np.float64)
     if u.ndim != 2 or u.shape[1] < K:
@@ -310,13 +330,13 @@ def SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a,
         raise ValueError("Incorrect dimensions for matrix multiplication (a'*(u_max - u(:, t))).")
     if n > 12:
         raise ValueError("this engine supports at most 12 NPIs")
-    sp = np.zeros((batch.SIM_PRM_COUNT, 1))
+    sp = np.zeros((_SIM_PRM_COUNT, 1))
     for name, v in (("s0", s0), ("i0", i0), ("alpha0", alpha0), ("alpha_min", alpha_min), ("alpha_max", alpha_max),
                     ("gamma", gamma), ("b", b), ("beta", beta), ("s_noise_std", s_noise_std), ("i_noise_std", i_noise_std),
                     ("alpha_noise_std", alpha_noise_std), ("dt", dt)):
-        sp[batch.SIM_FIELDS[name], 0] = float(v)
-    sp[batch.SIM_A:batch.SIM_A + n, 0] = a
-    sp[batch.SIM_U_MAX:batch.SIM_U_MAX + n, 0] = u_max
+        sp[_SIM_FIELDS[name], 0] = float(v)
+    sp[_SIM_A:_SIM_A + n, 0] = a
+    sp[_SIM_U_MAX:_SIM_U_MAX + n, 0] = u_max
     z = None
     if noise is not None:
         z = np.asarray(noise, dtype=np.float64)
@@ -324,13 +344,19 @@ def SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a,
             raise ValueError("noise must be 3 x K")
     elif float(s_noise_std) != 0.0 or float(i_noise_std) != 0.0 or float(alpha_noise_std) != 0.0:
         z = (rng or np.random.default_rng()).standard_normal((3, K))
-    zz = None if z is None else np.ascontiguousarray(z.T.reshape(K, 3, 1))
-    out = batch.sialpha_sim(np.ascontiguousarray(u[:, :K].T.reshape(K, n, 1)), sp, z=zz, device=device)
-    return tuple(out[k].cpu().numpy().reshape(1, K) for k in ("s", "i", "alpha"))
+    zz = None if z is None else np.ascontiguousarray(z.T)                 # [K][3][1]
+    uu = np.ascontiguousarray(u[:, :K].T)                                 # [K][n_npi][1]
+    d = _lib.SimDesc()
+    d.abi_version, d.B, d.K, d.Su, d.n_npi, d.noise = 1, 1, K, 1, n, int(zz is not None)
+    out = [np.zeros((1, K)) for _ in range(3)]
+    err = C.create_string_buffer(256)
+    rc = _lib.lib().epi_sialpha_sim_host(C.byref(d), None, _vp(uu), _vp(sp), _vp(zz), _vp(out[0]), _vp(out[1]), _vp(out[2]),
+                                         None, None, _dev_index(device), err)
+    _lib.check(rc, err)
+    return tuple(out)
 
 
 def _seirp(per_step, init, T, dt, sat, device):
-    from . import batch
     K = _matlab_round(float(T) / float(dt))
     if K < 1:
         raise IndexError("Index exceeds the number of array elements (s(1) = s0 with K = 0).")
@@ -340,13 +366,17 @@ def _seirp(per_step, init, T, dt, sat, device):
             continue
         a = _per_step(name, v, K - 1)
         par[:min(K, a.shape[0]), j, 0] = a[:K]
-    out = batch.seirp_sim(par, np.asarray(init, dtype=np.float64).reshape(5, 1), float(dt), K,
-                          sat=None if sat is None else np.asarray(sat, dtype=np.float64).reshape(6, 1), device=device)
-    o = out.cpu().numpy()
-    return tuple(o[:, q, 0].reshape(1, K) for q in range(5))
+    ini = np.ascontiguousarray(np.asarray(init, dtype=np.float64).reshape(5, 1))
+    st = None if sat is None else np.ascontiguousarray(np.asarray(sat, dtype=np.float64).reshape(6, 1))
+    o = np.zeros((K, 5, 1))
+    err = C.create_string_buffer(256)
+    rc = _lib.lib().epi_seirp_sim_host(1, K, K, float(dt), int(st is not None), 0, _vp(par), _vp(ini), _vp(st), _vp(o),
+                                       _dev_index(device), err)
+    _lib.check(rc, err)
+    return tuple(o[:, q, 0].reshape(1, K).copy() for q in range(5))
 
 
-def SEIRP(alpha_e, alpha_i, kappa, rho, beta, mu, gamma, s0, e0, i0, r0, p0, T, dt, device="cuda:0"):
+def SEIRP(alpha_e, alpha_i, kappa, rho, beta, mu, gamma, s0, e0, i0, r0, p0, T, dt, device=0):
     """[s, e, i, r, p] = SEIRP(alpha_e, alpha_i, kappa, rho, beta, mu, gamma, s0, e0, i0, r0, p0, T, dt)
     -- Tools/SEIRP.m:1 (forward Euler; K = round(T/dt) samples, the first one is the initial condition; the seven
     parameters are per-step arrays of at least K-1 elements)."""
@@ -355,7 +385,7 @@ def SEIRP(alpha_e, alpha_i, kappa, rho, beta, mu, gamma, s0, e0, i0, r0, p0, T, 
 
 
 def SEIRPSaturatedResource(alpha_e, alpha_i, kappa, rho, gamma, s0, e0, i0, r0, p0, T, dt, beta_0, beta_s, mu_0, mu_s,
-                           sigma, i_0, device="cuda:0"):
+                           sigma, i_0, device=0):
     """[s, e, i, r, p] = SEIRPSaturatedResource(alpha_e, alpha_i, kappa, rho, gamma, s0, e0, i0, r0, p0, T, dt, beta_0,
     beta_s, mu_0, mu_s, sigma, i_0) -- Tools/SEIRPSaturatedResource.m:1 (recovery and death rates gated by
     tanh((i - i_0)/sigma), :27-29)."""
@@ -363,12 +393,22 @@ def SEIRPSaturatedResource(alpha_e, alpha_i, kappa, rho, gamma, s0, e0, i0, r0, 
                    ("gamma", gamma)), (s0, e0, i0, r0, p0), T, dt, (beta_0, beta_s, mu_0, mu_s, sigma, i_0), device)
 
 
-def NPICost(newcases, inputs, weights, device="cuda:0"):
+def _npi_cost_host(nc, u_tn, w, device):
+    """nc [T], u_tn [T][n], w [T][n] or [n] -> (J0, J1) through epi_npi_cost_host (one chain)."""
+    T, n = u_tn.shape
+    J0, J1 = np.zeros(1), np.zeros(1)
+    err = C.create_string_buffer(256)
+    rc = _lib.lib().epi_npi_cost_host(1, T, n, 1, int(w.ndim == 2), None, _vp(nc), _vp(u_tn), _vp(w), _vp(J0), _vp(J1),
+                                      _dev_index(device), err)
+    _lib.check(rc, err)
+    return float(J0[0]), float(J1[0])
+
+
+def NPICost(newcases, inputs, weights, device=0):
     """[J0, J1] = NPICost(newcases, inputs, weights) -- Tools/NPICost.m:1: J0 = mean(newcases),
     J1 = mean(weights(:).*inputs(:)).  inputs and weights are n_npi x T (weights may also be n_npi x 1: implicit
     expansion of `weights .* inputs`)."""
-    from . import batch
-    nc = np.asarray(newcases, dtype=np.float64).reshape(-1)
+    nc = np.ascontiguousarray(np.asarray(newcases, dtype=np.float64).reshape(-1))
     u = np.asarray(inputs, dtype=np.float64); w = np.asarray(weights, dtype=np.float64)
     if u.ndim != 2:
         raise ValueError("inputs must be n_npi x T")
@@ -377,12 +417,11 @@ def NPICost(newcases, inputs, weights, device="cuda:0"):
         w = w.reshape(-1, 1)
     if w.shape not in ((n, T), (n, 1)):
         raise ValueError("Arrays have incompatible sizes for this operation (weights .* inputs).")
+    u_tn = np.ascontiguousarray(u.T)
+    wd = np.ascontiguousarray(w.T) if (w.shape[1] == T and T > 1) else np.ascontiguousarray(w[:, 0])
     if nc.shape[0] == T:
-        wd = np.ascontiguousarray(w.T.reshape(T, n, 1)) if w.shape[1] == T and T > 1 else np.ascontiguousarray(w[:, :1].reshape(n, 1))
-        J0, J1 = batch.npi_cost(nc.reshape(T, 1), np.ascontiguousarray(u.T.reshape(T, n, 1)), wd, device=device)
-        return float(J0.cpu()[0]), float(J1.cpu()[0])
+        return _npi_cost_host(nc, u_tn, wd, device)
     # newcases and inputs of different lengths are legal in the .m (two independent means): two calls
-    J0, _ = batch.npi_cost(nc.reshape(-1, 1), np.zeros((nc.shape[0], 1, 1)), np.zeros((1, 1)), device=device)
-    wd = np.ascontiguousarray(w.T.reshape(T, n, 1)) if w.shape[1] == T and T > 1 else np.ascontiguousarray(w[:, :1].reshape(n, 1))
-    _, J1 = batch.npi_cost(np.zeros((T, 1)), np.ascontiguousarray(u.T.reshape(T, n, 1)), wd, device=device)
-    return float(J0.cpu()[0]), float(J1.cpu()[0])
+    J0, _ = _npi_cost_host(nc, np.zeros((nc.shape[0], 1)), np.zeros(1), device)
+    _, J1 = _npi_cost_host(np.zeros(T), u_tn, wd, device)
+    return J0, J1

@@ -346,6 +346,18 @@ int epi_seirp_sim_device(int32_t B, int32_t K, int32_t par_steps, double dt, int
                          int32_t integrator, const double *par, const double *init, const double *sat,
                          double *out, void *stream, char *err);
 
+/* Host-pointer variants of the three entry points above (same arrays in host memory; the library stages them through
+ * device `device` and synchronises): what a MEX gateway for SIalpha_Controlled.m / SEIRP.m / SEIRPSaturatedResource.m /
+ * NPICost.m binds (matlab/epiekf_sim_mex.cpp). */
+int epi_sialpha_sim_host(const epi_sim_desc *d, const int32_t *u_series, const double *u, const double *sp,
+                         const double *z, double *s, double *i, double *alpha, double *J0, double *J1, int device,
+                         char *err);
+int epi_seirp_sim_host(int32_t B, int32_t K, int32_t par_steps, double dt, int32_t saturated, int32_t integrator,
+                       const double *par, const double *init, const double *sat, double *out, int device, char *err);
+int epi_npi_cost_host(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t weights_per_day, const int32_t *u_series,
+                      const double *newcases, const double *inputs, const double *weights, double *J0, double *J1,
+                      int device, char *err);
+
 /* Measurement utility (not part of the reference's interface): copies n doubles src -> dst with the filter
  * kernels' access shape (8 B per lane); used to calibrate the HBM traffic counters on a known byte count. */
 int epi_calib_copy_f64_device(const double *src, double *dst, size_t n, void *stream, char *err);

@@ -13,6 +13,9 @@ typedef size_t mwSize;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 typedef enum { mxDOUBLE_CLASS = 6 } mxClassID;
 double *mxGetPr(const mxArray *pa);
+int mxGetString(const mxArray *pa, char *str, mwSize strlen);
+bool mxIsEmpty(const mxArray *pa);
+void mxDestroyArray(mxArray *pa);
 double mxGetScalar(const mxArray *pa);
 size_t mxGetM(const mxArray *pa);
 size_t mxGetN(const mxArray *pa);

@@ -221,7 +221,7 @@ def test_mex_gateways_compile_against_the_abi_header():
     cxx = shutil.which("g++")
     if not cxx:
         pytest.skip("no g++")
-    for f in ("epiekf_mex.cpp", "epiekf_rt_mex.cpp", "epiekf_batch_mex.cpp"):
+    for f in ("epiekf_mex.cpp", "epiekf_rt_mex.cpp", "epiekf_batch_mex.cpp", "epiekf_sim_mex.cpp"):
         r = subprocess.run([cxx, "-std=c++11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
                             "-I" + os.path.join(H.ROOT, "tests", "mex_stub"), "-I" + os.path.join(H.ROOT, "include"),
                             os.path.join(H.ROOT, "matlab", f)], capture_output=True, text=True)
