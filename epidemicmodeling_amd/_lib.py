@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
-    "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_npi_cost_device", "epi_sialpha_sim_host", "epi_seirp_sim_host", "epi_npi_cost_host", "epi_calib_copy_f64_device",
+    "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_npi_cost_device", "epi_si_controlled_device", "epi_si_controlled_host", "epi_sialpha_sim_host", "epi_seirp_sim_host", "epi_npi_cost_host", "epi_calib_copy_f64_device",
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
     "epi_preprocess_workspace_bytes", "epi_preprocess_device", "epi_nnls_affine_fit_device",
 ]
@@ -151,6 +151,10 @@ def lib():
         h.epi_seirp_sim_host.restype = C.c_int
         h.epi_seirp_sim_host.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
+        h.epi_si_controlled_device.restype = C.c_int
+        h.epi_si_controlled_device.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double] + [C.c_void_p] * 5 + [C.c_void_p, C.c_char_p]
+        h.epi_si_controlled_host.restype = C.c_int
+        h.epi_si_controlled_host.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double] + [C.c_void_p] * 5 + [C.c_int, C.c_char_p]
         h.epi_npi_cost_host.restype = C.c_int
         h.epi_npi_cost_host.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 6 + [C.c_int, C.c_char_p]
         h.epi_rt_expfit_validate.restype = C.c_int

@@ -266,6 +266,25 @@ def pareto_front(J0, J1, n_regions):
     return on.bool(), io
 
 
+def si_controlled(alpha, beta, s0, i0, K, dt, alpha_series=None, device="cuda:0"):
+    """Batched Tools/SI_Controlled.m: alpha [K-1, Sa], beta / s0 / i0 [B].  Returns (s, i) torch [K, B]."""
+    dev = torch.device(device)
+    t = lambda a, dt_=torch.float64: None if a is None else (a.contiguous() if isinstance(a, torch.Tensor) else
+                                                             torch.as_tensor(np.ascontiguousarray(a), dtype=dt_).to(dev))
+    al, ser = t(alpha), t(alpha_series, torch.int32)
+    prm = t(np.stack([np.asarray(beta, dtype=np.float64), np.asarray(s0, dtype=np.float64), np.asarray(i0, dtype=np.float64)]))
+    B = prm.shape[1]
+    if al.shape[0] < K - 1:
+        raise IndexError("Index exceeds the number of array elements (alpha).")
+    s = torch.empty((K, B), dtype=torch.float64, device=dev); i = torch.empty_like(s)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+    rc = _lib.lib().epi_si_controlled_device(B, int(K), al.shape[1], float(dt), _ptr(ser), _ptr(al), _ptr(prm), _ptr(s), _ptr(i),
+                                             C.c_void_p(st.cuda_stream), err)
+    _lib.check(rc, err)
+    return s, i
+
+
 def npi_cost(newcases, inputs, weights, u_series=None, device="cuda:0"):
     """Batched Tools/NPICost.m: newcases [T, B], inputs [T, n_npi, Su], weights [T, n_npi, B] or [n_npi, B] (the same
     every day).  Returns (J0, J1) torch [B]."""

@@ -1326,6 +1326,19 @@ int epi_npi_cost_device(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t
     return EPI_OK;
 }
 
+int epi_si_controlled_device(int32_t B, int32_t K, int32_t Sa, double dt, const int32_t *alpha_series, const double *alpha,
+                             const double *prm, double *s, double *i, void *stream, char *err)
+{
+    if (B < 1 || K < 1 || Sa < 1 || !prm || !s || !i || (K > 1 && !alpha) || (!alpha_series && Sa != B)) {
+        set_err(err, "bad SI_Controlled arguments"); return EPI_ERR_BAD_ARG;
+    }
+    hipLaunchKernelGGL(si_controlled, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, K, Sa, dt, alpha_series,
+                       alpha, prm, s, i);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "si_controlled launch");
+    return EPI_OK;
+}
+
 // ---- host-pointer variants of the simulators and the cost (what a MEX gateway binds: matlab/epiekf_sim_mex.cpp) ----
 namespace {
 struct HostStage {   // device copies of host arrays for one call; frees everything on destruction
@@ -1393,6 +1406,21 @@ int epi_seirp_sim_host(int32_t B, int32_t K, int32_t par_steps, double dt, int32
     if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
     return h.finish(epi_seirp_sim_device(B, K, par_steps, dt, saturated, integrator, (const double *)dp, (const double *)di,
                                          (const double *)ds, (double *)dout, nullptr, err), err);
+}
+
+int epi_si_controlled_host(int32_t B, int32_t K, int32_t Sa, double dt, const int32_t *alpha_series, const double *alpha,
+                           const double *prm, double *s, double *i, int device, char *err)
+{
+    if (B < 1 || K < 1 || Sa < 1) { set_err(err, "bad SI_Controlled arguments"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    HostStage h;
+    const void *das = h.in(alpha_series, (size_t)B * 4), *da = h.in(alpha, (size_t)(K > 1 ? K - 1 : 1) * Sa * 8);
+    const void *dp = h.in(prm, (size_t)3 * B * 8);
+    void *ds = h.out(s, (size_t)K * B * 8), *di = h.out(i, (size_t)K * B * 8);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_si_controlled_device(B, K, Sa, dt, (const int32_t *)das, (const double *)da, (const double *)dp,
+                                             (double *)ds, (double *)di, nullptr, err), err);
 }
 
 int epi_npi_cost_host(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t weights_per_day, const int32_t *u_series,

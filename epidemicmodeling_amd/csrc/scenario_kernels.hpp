@@ -164,3 +164,24 @@ __global__ __launch_bounds__(256) void npi_cost(int B, int T, int n_npi, int Su,
     J0[c] = a0 / (double)T;
     J1[c] = a1 / (double)((size_t)n_npi * (size_t)T);
 }
+
+// Tools/SI_Controlled.m:12-23, one lane per chain: 2-state forward Euler with a time-dependent infection rate; the
+// first sample is the initial condition (:15-16)
+__global__ __launch_bounds__(256) void si_controlled(int B, int K, int Sa, double dt, const int32_t *__restrict__ a_series,
+                                                     const double *__restrict__ alpha, const double *__restrict__ prm,
+                                                     double *__restrict__ s_out, double *__restrict__ i_out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    const int sa = a_series ? a_series[c] : c;
+    const double beta = prm[c];
+    double s = prm[(size_t)B + c], i = prm[(size_t)2 * B + c];
+    s_out[c] = s; i_out[c] = i;
+    for (int t = 0; t < K - 1; t++) {
+        const double al = alpha[(size_t)t * Sa + sa];
+        const double sn = fmax(0.0, fmin(1.0, s - dt * al * s * i));                       // :21
+        const double in = fmax(0.0, fmin(1.0, i + dt * (al * s * i - beta * i)));          // :22
+        s = sn; i = in;
+        s_out[(size_t)(t + 1) * B + c] = s; i_out[(size_t)(t + 1) * B + c] = i;
+    }
+}

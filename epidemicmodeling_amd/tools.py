@@ -356,6 +356,21 @@ def SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a,
     return tuple(out)
 
 
+def SI_Controlled(alpha, beta, s0, i0, K, dt, device=0):
+    """[s, i] = SI_Controlled(alpha, beta, s0, i0, K, dt) -- Tools/SI_Controlled.m:1 (2-state forward Euler with a
+    time-dependent infection rate alpha(1 : K-1); K samples, the first one is the initial condition)."""
+    K = int(K)
+    if K < 1:
+        raise IndexError("Index exceeds the number of array elements (s(1) = s0 with K = 0).")
+    al = np.ascontiguousarray(_per_step("alpha", alpha, K - 1)[:max(K - 1, 1)]) if K > 1 else np.zeros(1)
+    prm = np.array([[float(beta)], [float(s0)], [float(i0)]])
+    s, i = np.zeros((1, K)), np.zeros((1, K))
+    err = C.create_string_buffer(256)
+    rc = _lib.lib().epi_si_controlled_host(1, K, 1, float(dt), None, _vp(al), _vp(prm), _vp(s), _vp(i), _dev_index(device), err)
+    _lib.check(rc, err)
+    return s, i
+
+
 def _seirp(per_step, init, T, dt, sat, device):
     K = _matlab_round(float(T) / float(dt))
     if K < 1:

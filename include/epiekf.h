@@ -346,6 +346,14 @@ int epi_seirp_sim_device(int32_t B, int32_t K, int32_t par_steps, double dt, int
                          int32_t integrator, const double *par, const double *init, const double *sat,
                          double *out, void *stream, char *err);
 
+/* Tools/SI_Controlled.m:1-23 batched: 2-state forward Euler with a time-dependent infection rate.  alpha [K-1][Sa]
+ * (the loop reads alpha(1 : K-1)) with alpha_series [B] or NULL (identity, Sa == B); prm [3][B] = beta, s0, i0;
+ * outputs s, i [K][B], the first sample being the initial condition (:15-16). */
+int epi_si_controlled_device(int32_t B, int32_t K, int32_t Sa, double dt, const int32_t *alpha_series, const double *alpha,
+                             const double *prm, double *s, double *i, void *stream, char *err);
+int epi_si_controlled_host(int32_t B, int32_t K, int32_t Sa, double dt, const int32_t *alpha_series, const double *alpha,
+                           const double *prm, double *s, double *i, int device, char *err);
+
 /* Host-pointer variants of the three entry points above (same arrays in host memory; the library stages them through
  * device `device` and synchronises): what a MEX gateway for SIalpha_Controlled.m / SEIRP.m / SEIRPSaturatedResource.m /
  * NPICost.m binds (matlab/epiekf_sim_mex.cpp). */

@@ -3,6 +3,7 @@
 //   [s, i, alpha]     = epiekf_sim_mex('sialpha', u, sp, z)            u n_npi x K, sp 48 x 1 (EPI_SIM_* rows), z 3 x K or []
 //   out               = epiekf_sim_mex('seirp', par, init, dt, sat)    par 7 x K, init 5 x 1, sat 6 x 1 or []; out 5 x K
 //   [J0, J1]          = epiekf_sim_mex('npicost', newcases, inputs, weights)   inputs n x T, weights n x T or n x 1
+//   [s, i]            = epiekf_sim_mex('si', alpha, [beta; s0; i0], K, dt)      alpha with at least K-1 elements
 // With B = 1 MATLAB's column-major arrays ARE the ABI's [K][rows][1] arrays and are passed straight through.
 // Build on a MATLAB host:  mex -I../include epiekf_sim_mex.cpp -L../epidemicmodeling_amd -lepiekf
 #include <string.h>
@@ -52,6 +53,16 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         fail_if(epi_npi_cost_host(1, (int32_t)T, (int32_t)n, 1, (wn == T && T > 1) ? 1 : 0, NULL, mxGetPr(prhs[1]), mxGetPr(prhs[2]),
                                   mxGetPr(prhs[3]), mxGetPr(plhs[0]), mxGetPr(j1), /*device=*/0, err), err);
         if (nlhs > 1) plhs[1] = j1; else mxDestroyArray(j1);
+    } else if (strcmp(cmd, "si") == 0) {
+        if (nrhs != 5) mexErrMsgTxt("epiekf_sim_mex('si', alpha, prm, K, dt): 5 inputs expected");
+        const mwSize K = (mwSize)mxGetScalar(prhs[3]);
+        if (K < 1 || (K > 1 && mxGetNumberOfElements(prhs[1]) < K - 1)) mexErrMsgTxt("Index exceeds the number of array elements.");
+        if (mxGetNumberOfElements(prhs[2]) != 3) mexErrMsgTxt("prm must be [beta; s0; i0]");
+        plhs[0] = mxCreateDoubleMatrix(1, K, mxREAL);
+        mxArray *iv = mxCreateDoubleMatrix(1, K, mxREAL);
+        fail_if(epi_si_controlled_host(1, (int32_t)K, 1, mxGetScalar(prhs[4]), NULL, mxGetPr(prhs[1]), mxGetPr(prhs[2]),
+                                       mxGetPr(plhs[0]), mxGetPr(iv), /*device=*/0, err), err);
+        if (nlhs > 1) plhs[1] = iv; else mxDestroyArray(iv);
     } else {
         mexErrMsgTxt("epiekf_sim_mex: unknown command");
     }
