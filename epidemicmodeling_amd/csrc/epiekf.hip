@@ -177,14 +177,22 @@ EPI_DEV void load_u(const KArgs &a, int t, int su, double (&u)[kNpi])
 {
     const unsigned voff = (unsigned)su * 8u, rowb = (unsigned)a.Su * 8u;
     const rsrc_t r = mk_rsrc(a.u + (size_t)t * a.n_npi * a.Su, (unsigned)a.n_npi * rowb);
+    // rows k >= n_npi lie beyond the descriptor's range: the hardware bounds check returns 0.0 for them, which is the
+    // padding value -- twelve unconditional loads instead of twelve scalar branches (the check includes the SGPR row
+    // offset on gfx950: profiles/bounds_probe/probe.hip)
 #pragma unroll
-    for (int k = 0; k < kNpi; k++) u[k] = (k < a.n_npi) ? bld(r, voff, (unsigned)k * rowb) : 0.0;
+    for (int k = 0; k < kNpi; k++) u[k] = bld(r, voff, (unsigned)k * rowb);
 }
 EPI_DEV void store_u(double *__restrict__ dst, const KArgs &a, int t, const Lay &l, const double (&u)[kNpi])
 {
     if (!dst) return;
     unsigned voff, rowb;
     const rsrc_t r = lay_slice(dst, t, (unsigned)a.n_npi, l, voff, rowb);
+    if (a.n_npi == kNpi) {                    // the usual case: one scalar branch instead of twelve
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) bst(r, voff, (unsigned)k * rowb, u[k]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < kNpi; k++)
         if (k < a.n_npi) bst(r, voff, (unsigned)k * rowb, u[k]);
