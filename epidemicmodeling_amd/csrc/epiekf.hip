@@ -369,8 +369,10 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 // ensemble), so they keep 256 threads.
 template <int M>
 constexpr int pinv_wg() { return M >= 6 ? 64 : 256; }
+// Three waves per SIMD (168 VGPRs): the 6 x 6 Jacobi then spills ~10 doubles of cold state (76 B/lane of scratch), and
+// the third wave still fills more VALU issue slots than the spills cost -- 6.2 -> 5.9 ms on the headline sweep.
 template <int M>
-__global__ __launch_bounds__(pinv_wg<M>()) void eks_pinv(const KArgs a)
+__global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
 {
     // grid: x = pinv_wg<M>()-chain tiles of the chain range, y = step; a workgroup shares one step => uniform row bases
     const int cl = blockIdx.x * blockDim.x + threadIdx.x;
