@@ -266,7 +266,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args), "kernel": dom,
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes,
                          "limiter": {"ekf_fwd": "HBM writes (store pattern) + lone-wave latency",
-                                     "eks_pinv": "fp64 VALU issue (Jacobi; SIMD VALU busy 80 % of the kernel's duration, profiles/r01/valu_summary.json) -- not HBM",
+                                     "eks_pinv": "fp64 VALU issue (Jacobi; SIMD VALU busy 87 % of the kernel's duration, profiles/r01/valu_summary.json) -- not HBM",
                                      "eks_bwd": "lone-wave latency + HBM"}[dom]},
             "kernels": {**{k + "_ms": v for k, v in ms.items()},
                         **{k + "_GBs": alg[k] * steps_per_pass / (ms[k] * 1e-3) / 1e9 for k in ms},
