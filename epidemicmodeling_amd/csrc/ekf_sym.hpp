@@ -183,7 +183,7 @@ EPI_DEV void predict_cov_sym(const double (&A)[M * M], const double (&Pp)[M * (M
 //         SIMD, nothing else fits beside it.
 // LP = 1: the four 12-vectors of `params` live in LDS next to the windows and every LDS array is sized by the lanes the
 //         workgroup really uses (kPipeLanes = 40) -- 298 VGPRs and (3 L + 48) * 40 * 8 bytes of LDS, so that four such
-//         waves fit a CU AND an eks_pinv wave (194 VGPRs, no LDS) fits beside each of them: the pipelined launch
+//         waves fit a CU AND an eks_pinv wave (168 VGPRs, no LDS) fits beside each of them: the pipelined launch
 //         (epi_batch_desc.chunks = -2) runs one half's eks_pinv grid in the issue slots the other half's forward waves
 //         leave idle.
 template <int M, int FLIP, int LP>

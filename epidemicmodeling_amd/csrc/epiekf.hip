@@ -951,7 +951,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
     if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1) {
         // Pipelined halves.  The forward kernel of the second half and the eks_pinv grid of the first half are in flight
         // together, and -- because this forward variant (LDS-resident model constants, LDS sized by the lanes used)
-        // needs 298 VGPRs and eks_pinv 194 -- they share SIMDs: the VALU-bound Jacobi runs in the issue slots the
+        // needs 298 VGPRs and eks_pinv 168 -- they share SIMDs: the VALU-bound Jacobi runs in the issue slots the
         // latency-bound filter waves leave idle.  The backward kernel (492 VGPRs) cannot share; it follows as one launch.
         int dev = 0, cus = 0;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
