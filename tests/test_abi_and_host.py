@@ -231,3 +231,37 @@ def test_mex_gateways_compile_against_the_abi_header():
                         "-I" + os.path.join(H.ROOT, "include"), "-x", "c", "-"], input='#include "epiekf.h"\nint main(void){epi_batch_desc d; d.lane_block = 0; return d.lane_block + (int)sizeof(epi_outputs) * 0;}\n',
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_simulator_entry_points_reject_bad_arguments_without_a_gpu(hip_lib):
+    """The simulator / cost entry points validate their arguments before any HIP call (-5 = EPI_ERR_BAD_ARG), and the
+    Tools-named mirrors raise MATLAB's own kind of error for inputs the .m files would choke on -- all without a GPU."""
+    from epidemicmodeling_amd import _lib, tools
+    err = C.create_string_buffer(256)
+    one = np.zeros(8)
+    p = one.ctypes.data
+    assert hip_lib.epi_npi_cost_device(0, 5, 3, 1, 0, None, p, p, p, p, p, None, err) == -5
+    assert hip_lib.epi_npi_cost_device(4, 5, 3, 2, 0, None, p, p, p, p, p, None, err) == -5      # Su != B without a series map
+    assert hip_lib.epi_npi_cost_device(4, 5, 3, 4, 0, None, None, p, p, p, p, None, err) == -5
+    assert hip_lib.epi_npi_cost_host(1, 0, 3, 1, 0, None, p, p, p, p, p, 0, err) == -5
+    assert hip_lib.epi_si_controlled_device(1, 0, 1, 0.1, None, p, p, p, p, None, err) == -5
+    assert hip_lib.epi_si_controlled_device(3, 5, 2, 0.1, None, p, p, p, p, None, err) == -5     # Sa != B without a series map
+    assert hip_lib.epi_si_controlled_host(0, 5, 1, 0.1, None, p, p, p, p, 0, err) == -5
+    assert hip_lib.epi_seirp_sim_host(1, 0, 1, 0.1, 0, 0, p, p, None, p, 0, err) == -5
+    d = _lib.SimDesc()
+    d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, 1, 0, 1, 3
+    assert hip_lib.epi_sialpha_sim_host(C.byref(d), None, p, p, None, p, p, p, None, None, 0, err) == -5
+    d.K, d.u_block = 4, 8
+    assert hip_lib.epi_sialpha_sim_host(C.byref(d), None, p, p, None, p, p, p, None, None, 0, err) == -5
+    u = np.zeros((3, 10))
+    with pytest.raises(IndexError):                  # u(:, t) beyond size(u, 2)
+        tools.SIalpha_Controlled(u, 0.9, 0.1, 1.0, [1, 1, 1], 0, 10, 0.1, [0, 0, 0], 0, 0.1, 0, 0, 0, 11, 1.0)
+    with pytest.raises(ValueError):                  # a'*(u_max - u(:, t)) with mismatched lengths
+        tools.SIalpha_Controlled(u, 0.9, 0.1, 1.0, [1, 1], 0, 10, 0.1, [0, 0, 0], 0, 0.1, 0, 0, 0, 5, 1.0)
+    with pytest.raises(IndexError):                  # alpha(t) beyond numel(alpha)
+        tools.SI_Controlled(np.ones(3), 0.05, 0.9, 0.1, 10, 0.1)
+    with pytest.raises(IndexError):                  # scalar parameters, K-1 > 1 steps
+        tools.SEIRP(0.6, 0.005, 0.05, 0.08, 0.1, 0.02, 0.001, 0.99, 0.01, 0, 0, 0, 10, 0.1)
+    with pytest.raises(ValueError):                  # weights .* inputs with incompatible sizes
+        tools.NPICost(np.ones(10), u, np.ones((3, 4)))
+    assert tools._matlab_round(2.5) == 3 and tools._matlab_round(-2.5) == -3 and tools._matlab_round(36.5 / 0.1) == 365
