@@ -105,6 +105,23 @@ def main():
         res.append({"stage": f"seirp_sim ({integ})", "param_sets": Bs, "steps": Ks, "ms": ms,
                     "ensemble_steps_per_s": Bs * Ks / (ms * 1e-3), "written_GBs": Bs * Ks * 5 * 8 / (ms * 1e-3) / 1e9})
 
+    # BASELINE config 1's model (testSIR01.m: SI_Controlled, K = 1500, dt = 0.1) as a 10 000-member ensemble, and
+    # NPICost over 75 000 chains x 520 days on its own
+    Bi, Ki = 10000, 1500
+    al = t(np.full((Ki - 1, Bi), 0.5) * (1 + 0.2 * rng.random((Ki - 1, Bi))))
+    ms = timed(lambda: batch.si_controlled(al, np.full(Bi, 0.05), np.full(Bi, 1 - 1e-6), np.full(Bi, 1e-6), Ki, 0.1, device=dev),
+               args.reps)
+    res.append({"stage": "si_controlled", "chains": Bi, "steps": Ki, "ms": ms, "ensemble_steps_per_s": Bi * Ki / (ms * 1e-3)})
+    del al
+    Bc, Tc = 75000, 520
+    ncs = torch.rand((Tc, Bc), dtype=torch.float64, device=dev)
+    uc = t(rng.integers(0, 4, size=(Tc, n, S)).astype(np.float64))
+    wc = torch.rand((n, Bc), dtype=torch.float64, device=dev)
+    ser = t(np.repeat(np.arange(S), Bc // S).astype(np.int32)).to(torch.int32)
+    ms = timed(lambda: batch.npi_cost(ncs, uc, wc, u_series=ser, device=dev), args.reps)
+    res.append({"stage": "npi_cost", "chains": Bc, "days": Tc, "ms": ms, "read_GBs": Bc * Tc * 8 / (ms * 1e-3) / 1e9})
+    del ncs, uc, wc
+
     if args.pipeline:
         from epidemicmodeling_amd import pipeline
         raw["cases"][:, -1] = np.cumsum(np.full(T, 40.0))
