@@ -223,6 +223,28 @@ def test_random_scenarios_match_the_oracle(gpu_device, data):
                       *[dp(v) for v in res])
         for q in range(5):
             assert np.array_equal(out[:, q, c], res[q]), (B, Ks, dt, c, q)
+    # SI_Controlled with shared infection-rate series, and NPICost on its own (weights per day or one column, shared inputs)
+    Bi = draw(st.integers(1, 90)); Ki = draw(st.integers(1, 50)); Sa = draw(st.integers(1, Bi))
+    al = rng.uniform(0.0, 3.0, (max(Ki - 1, 1), Sa)); ser = rng.integers(0, Sa, Bi).astype(np.int32) if Sa != Bi or draw(st.booleans()) else None
+    beta = rng.uniform(0.0, 0.5, Bi); s0 = rng.uniform(0.0, 1.0, Bi); i0 = rng.uniform(0.0, 1.0, Bi); dts = draw(st.sampled_from([0.1, 1.0, 2.5]))
+    gs, gi = (t.cpu().numpy() for t in batch.si_controlled(al, beta, s0, i0, Ki, dts, alpha_series=ser, device=gpu_device))
+    for c in {0, Bi // 2, Bi - 1}:
+        col = np.ascontiguousarray(al[:, c if ser is None else ser[c]])
+        rs, ri = np.zeros(Ki), np.zeros(Ki)
+        lib.orc_si_controlled(dp(col), C.c_double(beta[c]), C.c_double(s0[c]), C.c_double(i0[c]), C.c_int(Ki), C.c_double(dts), dp(rs), dp(ri))
+        assert np.array_equal(gs[:, c], rs) and np.array_equal(gi[:, c], ri), (Bi, Ki, Sa, c)
+    Bc = draw(st.integers(1, 90)); Tc = draw(st.integers(1, 40)); nn = draw(st.integers(1, 12)); Su = draw(st.integers(1, Bc))
+    ub = rng.integers(0, 5, size=(Tc, nn, Su)).astype(np.float64); nc = rng.random((Tc, Bc))
+    ser = rng.integers(0, Su, Bc).astype(np.int32) if Su != Bc or draw(st.booleans()) else None
+    per_day = draw(st.booleans())
+    wb = rng.random((Tc, nn, Bc)) if per_day else rng.random((nn, Bc))
+    g0, g1 = (t.cpu().numpy() for t in batch.npi_cost(nc, ub, wb, u_series=ser, device=gpu_device))
+    for c in {0, Bc // 2, Bc - 1}:
+        uc = np.asfortranarray(ub[:, :, c if ser is None else ser[c]].T)
+        wc = np.asfortranarray(wb[:, :, c].T) if per_day else np.asfortranarray(np.repeat(wb[:, c][:, None], Tc, axis=1))
+        J0, J1 = C.c_double(), C.c_double()
+        lib.orc_npi_cost(dp(np.ascontiguousarray(nc[:, c])), dp(uc), dp(wc), C.c_int(nn), C.c_int(Tc), C.byref(J0), C.byref(J1))
+        assert (g0[c], g1[c]) == (J0.value, J1.value), (Bc, Tc, nn, Su, per_day, c)
 
 
 @settings(max_examples=_N or 40, deadline=None, suppress_health_check=list(HealthCheck), derandomize=not _N)
