@@ -251,6 +251,7 @@ def main():
         achieved = dom_bytes / (ms[dom] * 1e-3) / 1e9
         step_bytes = (BYTES_PER_STEP_FULL[m] if full else 112 + 8 * (m + 12)) * steps_per_pass
         step_gbs = step_bytes / (sum(ms.values()) * 1e-3) / 1e9
+        traffic = pmc_traffic(dom, args)
         res = {
             "metric": "region-day EKF steps/sec (300 regions x 400 days x 250 costs)",
             "value": value, "unit": "region-day EKF steps/s", "n_gpus": world, "steps": args.steps,
@@ -263,7 +264,11 @@ def main():
                        "scoring_tail": bool(score),
                        "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather of (J0, J1) to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args), "kernel": dom,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
+                         # what the kernel actually moves (PMC bytes of the committed profile / this run's duration):
+                         # the smoother re-reads S+-, P+-, X, so its HBM throughput is ~2.5x the algorithmic figure
+                         "traffic_GBs": None if traffic is None else traffic / (ms[dom] * 1e-3) / 1e9,
+                         "traffic_frac_of_peak": None if traffic is None else traffic / (ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes,
                          "limiter": {"ekf_fwd": "HBM writes (store pattern) + lone-wave latency",
                                      "eks_pinv": "fp64 VALU issue (Jacobi; SIMD VALU busy 87 % of the kernel's duration, profiles/r01/valu_summary.json) -- not HBM",
