@@ -31,11 +31,18 @@ template <int M> constexpr bool a_nz(int i, int k)
 }
 
 template <int M>
-EPI_DEV void store_sym(double *__restrict__ dst, int t, const Lay &l, const double (&P)[nsym<M>()])
+EPI_DEV void store_sym(double *__restrict__ dst, int t, const Lay &l, const double (&P)[nsym<M>()], bool upper_only = false)
 {
     if (!dst) return;
     unsigned voff, rowb;
     const rsrc_t r = lay_slice(dst, t, M * M, l, voff, rowb);
+    if (upper_only) {      // workspace read back through load_sym / eks_pinv only: the mirror entries are never read
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i <= j; i++) bst(r, voff, (unsigned)IXM(i, j) * rowb, P[sidx(i, j)]);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         }
 
         store_vec<M>(a.S_MINUS, t, lay, sk_minus);
-        store_sym<M>(a.P_MINUS, t, lay, Pm);
+        store_sym<M>(a.P_MINUS, t, lay, Pm, (a.ws_upper & 1) != 0);
 
         double C[M];
         obs_jacobian<M>(a.mf, sk_minus, C);                 // C(4:6) == 0 for m = 6
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         state_hard_margins<M>(p, sk_minus);
 
         store_vec<M>(a.S_PLUS, t, lay, sk_plus);
-        store_sym<M>(a.P_PLUS, t, lay, Pp);
+        store_sym<M>(a.P_PLUS, t, lay, Pp, (a.ws_upper & 2) != 0);
         store_vec<M>(a.K_GAIN, t, lay, K);
         if (a.innovations) a.innovations[lay_scalar(t, lay)] = innov;
 

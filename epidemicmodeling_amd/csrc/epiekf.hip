@@ -37,6 +37,9 @@ struct KArgs {
     const double *s_init, *Ps_init, *s_final, *Ps_final, *Q;   // already swapped for flipped models
     // forward quantities (outputs or workspace; never NULL)
     double *S_MINUS, *S_PLUS, *P_MINUS, *P_PLUS;
+    // bit 0 / bit 1: P_MINUS / P_PLUS is workspace, not a caller's output -- the packed kernels then store its upper
+    // triangle only (what eks_pinv and eks_bwd_sym read back): 15 of 36 rows less to write per array and step
+    int ws_upper;
     // optional outputs (NULL = not stored)
     double *u_opt, *u_opt_smooth, *S_SMOOTH, *P_SMOOTH, *K_GAIN, *innovations, *rho;
     int32_t *pinv_rank, *status;
@@ -1116,6 +1119,7 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     ka.S_PLUS = (om & EPI_OUT_S_PLUS) ? out->S_PLUS : (double *)(ws + wl.s_plus);
     ka.P_MINUS = (om & EPI_OUT_P_MINUS) ? out->P_MINUS : (double *)(ws + wl.p_minus);
     ka.P_PLUS = (om & EPI_OUT_P_PLUS) ? out->P_PLUS : (double *)(ws + wl.p_plus);
+    ka.ws_upper = ((om & EPI_OUT_P_MINUS) ? 0 : 1) | ((om & EPI_OUT_P_PLUS) ? 0 : 2);
     ka.u_opt = sel(EPI_OUT_U_OPT, out->u_opt);
     ka.u_opt_smooth = has_uos ? sel(EPI_OUT_U_OPT_SMOOTH, out->u_opt_smooth) : nullptr;
     ka.S_SMOOTH = sel(EPI_OUT_S_SMOOTH, out->S_SMOOTH);
