@@ -414,16 +414,23 @@ EPI_DEV bool jacobi_left_alone(bool dead_p, bool dead_q, double dp, double dq, d
 }
 
 // a: symmetric, only the upper triangle (i <= j) is read/updated.  Returns true if the sweep cap was hit.
-template <int M>
-EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
+// BZS > 0: the accumulators b and z (Rutishauser) live in LDS, one column per lane with a stride of BZS doubles (bz
+// points at this lane's column: b(i) = bz[i*BZS], z(i) = bz[(M+i)*BZS]) -- they are touched twice per rotation and once
+// per sweep, and 24 registers less let three 6 x 6 waves share a SIMD without scratch.
+template <int M, int BZS = 0>
+EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M], double *bz = nullptr)
 {
-    double b[M], z[M];
+    double b[BZS ? 1 : M], z[BZS ? 1 : M];
+    auto getb = [&](int i) { return BZS ? bz[i * BZS] : b[BZS ? 0 : i]; };
+    auto setb = [&](int i, double x) { if (BZS) bz[i * BZS] = x; else b[BZS ? 0 : i] = x; };
+    auto getz = [&](int i) { return BZS ? bz[(M + i) * BZS] : z[BZS ? 0 : i]; };
+    auto setz = [&](int i, double x) { if (BZS) bz[(M + i) * BZS] = x; else z[BZS ? 0 : i] = x; };
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
         for (int i = 0; i < M; i++) v[IXM(i, j)] = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-    for (int i = 0; i < M; i++) { b[i] = d[i] = a[IXM(i, i)]; z[i] = 0.0; }
+    for (int i = 0; i < M; i++) { d[i] = a[IXM(i, i)]; setb(i, d[i]); setz(i, 0.0); }
     bool capped = true;
     for (int sweep = 1; sweep <= kJacobiMaxSweeps; sweep++) {
         // sym_pinv discards every eigenpair below tol = M*eps(max|d|); an index is "dead" when its diagonal entry is
@@ -484,8 +491,8 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
                     const double s = t * c;
                     const double tau = (t * r) * ir;
                     const double h = t * apq;
-                    z[p] = z[p] - h;
-                    z[q] = z[q] + h;
+                    setz(p, getz(p) - h);
+                    setz(q, getz(q) + h);
                     d[p] = d[p] - h;
                     d[q] = d[q] + h;
 #pragma unroll
@@ -501,14 +508,14 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M])
             }
         }
 #pragma unroll
-        for (int i = 0; i < M; i++) { b[i] = b[i] + z[i]; d[i] = b[i]; z[i] = 0.0; }
+        for (int i = 0; i < M; i++) { const double bi = getb(i) + getz(i); setb(i, bi); d[i] = bi; setz(i, 0.0); }
     }
     return capped;
 }
 
 // X = pinv(A) for symmetric A; returns the rank kept.  *capped: Jacobi hit the sweep cap.
-template <int M>
-EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped)
+template <int M, int BZS = 0>
+EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped, double *bz = nullptr)
 {
     double a[M * M], d[M], v[M * M];
     double amax = 0.0;
@@ -523,7 +530,7 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped)
     for (int j = 0; j < M; j++)
 #pragma unroll
         for (int i = 0; i < M; i++) a[IXM(i, j)] = ldexp(A[IXM(i <= j ? i : j, i <= j ? j : i)], -e);
-    *capped = jacobi_eig<M>(a, d, v);
+    *capped = jacobi_eig<M, BZS>(a, d, v, bz);
     double smax = 0.0;
 #pragma unroll
     for (int i = 0; i < M; i++) smax = fmax(smax, fabs(d[i]));

@@ -372,8 +372,9 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
 // ensemble), so they keep 256 threads.
 template <int M>
 constexpr int pinv_wg() { return M >= 6 ? 64 : 256; }
-// Three waves per SIMD (168 VGPRs): the 6 x 6 Jacobi then spills ~10 doubles of cold state (76 B/lane of scratch), and
-// the third wave still fills more VALU issue slots than the spills cost -- 6.2 -> 5.9 ms on the headline sweep.
+// Three waves per SIMD (168 VGPRs): the third wave fills VALU issue slots two dependent fp64 chains leave idle (6.2 ->
+// 5.9 ms on the headline sweep with 76 B/lane of scratch; 5.8 ms and no scratch once the Jacobi's b/z accumulators
+// moved to LDS, 6 KB per wavefront).
 template <int M>
 __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
 {
@@ -411,7 +412,10 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     }
     double X[M * M];
     bool capped;
-    const int rank = sym_pinv<M>(P, X, &capped);           // :215
+    // 6 x 6: the Jacobi's b/z accumulators in LDS (one column per lane), see jacobi_eig
+    constexpr int BZS = (M >= 6) ? pinv_wg<M>() : 0;
+    __shared__ double bzs[BZS ? 2 * M * BZS : 1];
+    const int rank = sym_pinv<M, BZS>(P, X, &capped, bzs + threadIdx.x);           // :215
     {   // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
         constexpr int NSX = M * (M + 1) / 2;
         unsigned voff, rowb;
