@@ -120,9 +120,16 @@ def cpu_baseline(w, args):
     t0 = time.perf_counter()
     H.oracle_batch(ws, n_threads=cores)
     dt = time.perf_counter() - t0
+    # the same restatement on ONE thread (SURVEY.md 8d asks for both), ~3 s worth of chains
+    n1 = int(max(4, min(ws.B, ws.B * 3.0 / (dt * cores))))
+    w1 = w.select(np.linspace(0, w.B - 1, n1).astype(np.int64))
+    t1 = time.perf_counter()
+    H.oracle_batch(w1, n_threads=1)
+    dt1 = time.perf_counter() - t1
     return {"value": ws.B * ws.T / dt, "unit": "region-day EKF steps/s", "cores": cores, "kind": "port",
             "sample": f"{ws.B} of {w.B} chains (every {max(1, w.B // n)}th) x {ws.T} days, all 11 outputs, "
-                      f"OpenMP over chains, {dt:.1f} s; C restatement of Tools/*.m (MATLAB unavailable)"}
+                      f"OpenMP over chains, {dt:.1f} s; C restatement of Tools/*.m (MATLAB unavailable)",
+            "single_thread": {"value": w1.B * w1.T / dt1, "cores": 1, "sample": f"{w1.B} chains x {w1.T} days, {dt1:.1f} s"}}
 
 
 def main():
