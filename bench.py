@@ -100,6 +100,35 @@ def pmc_traffic(kernel, args):
     return None
 
 
+def measured_copy_bandwidth(dev):
+    """What this box's HBM delivers on a plain copy (state it beside the nominal 8 TB/s): 2 GiB read +
+    2 GiB written per launch, once with the filter kernels' own access shape (8 B per lane, the library's calibration
+    kernel) and once with torch's vectorised copy; HIP events, best of three, in GB/s of bytes moved."""
+    import ctypes as C
+    import torch
+    from epidemicmodeling_amd import _lib
+    n = 1 << 28
+    src = torch.rand(n, dtype=torch.float64, device=dev)
+    dst = torch.empty_like(src)
+    err = C.create_string_buffer(256)
+    st = torch.cuda.current_stream(dev)
+
+    def own():
+        _lib.check(_lib.lib().epi_calib_copy_f64_device(src.data_ptr(), dst.data_ptr(), n, C.c_void_p(st.cuda_stream), err), err)
+    out = {}
+    for name, fn in (("copy_8B_per_lane_GBs", own), ("copy_torch_GBs", lambda: dst.copy_(src))):
+        fn(); torch.cuda.synchronize(dev)
+        best = 1e9
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize(dev)
+            best = min(best, a.elapsed_time(b))
+        out[name] = 16.0 * n / (best * 1e-3) / 1e9
+    del src, dst
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(w, args):
     """The CPU oracle (C restatement of Tools/*.m, MATLAB unavailable) timed on this host's cores over a
     bounded sample of the same workload: every k-th chain, all days, all outputs."""
@@ -259,6 +288,7 @@ def main():
         step_bytes = (BYTES_PER_STEP_FULL[m] if full else 112 + 8 * (m + 12)) * steps_per_pass
         step_gbs = step_bytes / (sum(ms.values()) * 1e-3) / 1e9
         traffic = pmc_traffic(dom, args)
+        copy_bw = measured_copy_bandwidth(dev)
         res = {
             "metric": "region-day EKF steps/sec (300 regions x 400 days x 250 costs)",
             "value": value, "unit": "region-day EKF steps/s", "n_gpus": world, "steps": args.steps,
@@ -276,6 +306,7 @@ def main():
                          # the smoother re-reads S+-, P+-, X, so its HBM throughput is ~2.5x the algorithmic figure
                          "traffic_GBs": None if traffic is None else traffic / (ms[dom] * 1e-3) / 1e9,
                          "traffic_frac_of_peak": None if traffic is None else traffic / (ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "measured_copy": copy_bw,     # this box, this process: bytes read + written per second
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes,
                          "limiter": {"ekf_fwd": "HBM writes (store pattern) + lone-wave latency",
                                      "eks_pinv": "fp64 VALU issue (Jacobi; SIMD VALU busy 87 % of the kernel's duration, profiles/r01/valu_summary.json) -- not HBM",
