@@ -354,7 +354,9 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         winCov[head * stride] = cc;
         winCovN[head * stride] = ccn;
         const double sumN = ring_sum(winCovN, head, L, ccn, stride);
-        if (a.rho) a.rho[lay_scalar(t, lay)] = sumN / (double)cnt;
+        // rho keeps FILTER-step order also for the time-flipped wrappers: GenericEKF.m:233 squeezes it to T x 1 and
+        // Backward*.m:40 reverses a third dimension of size 1, i.e. nothing
+        if (a.rho) a.rho[lay_scalar(k, lay)] = sumN / (double)cnt;
         if (fixed_R) {
             if (beta != 1.0 && valid && k < T - 1) {
                 const double sumC = ring_sum(winCov, head, L, cc, stride);

@@ -344,7 +344,9 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
         winCov[head * kWave] = cc;
         winCovN[head * kWave] = ccn;
         const double sumN = ring_sum(winCovN, head, L, ccn);
-        if (a.rho) a.rho[lay_scalar(t, lay)] = sumN / (double)cnt;
+        // rho keeps FILTER-step order also for the time-flipped wrappers: GenericEKF.m:233 squeezes it to T x 1 and
+        // Backward*.m:40 reverses a third dimension of size 1, i.e. nothing
+        if (a.rho) a.rho[lay_scalar(k, lay)] = sumN / (double)cnt;
         if (fixed_R) {
             const bool adapt = GENERIC ? (beta != 1.0 && valid && k < T - 1) : (beta != 1.0 && valid);
             if (adapt) {

@@ -343,7 +343,13 @@ def backward_wrapper(u, x, model, params, s_init, Ps_init, s_final, Ps_final, w_
     u = np.asarray(u, dtype=np.float64); x = np.asarray(x, dtype=np.float64).reshape(-1)
     out = generic_ekf(u[:, ::-1], x[::-1], model, params, s_final, Ps_final, s_init, Ps_init,
                       w_bar, v_bar, Q_w, R_v, beta, gamma, inv_monitor_len, order)
-    return tuple(np.flip(o, axis=-1) for o in out)
+    # every output is reversed along its time axis EXCEPT rho: GenericExtendedKalmanFilter.m:233 has squeezed it to
+    # T x 1, and `rho_flipped(:, :, end:-1:1)` (SIAlphaModelBackwardEKF.m:40) indexes a third dimension of size 1 --
+    # `end` is 1 there, so MATLAB hands the column back un-reversed (filter-step order)
+    names = ("u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "P_MINUS", "P_PLUS", "P_SMOOTH", "K_GAIN",
+             "innovations", "rho", "ranks")
+    assert len(out) == len(names)
+    return tuple(o if n == "rho" else np.flip(o, axis=-1) for n, o in zip(names, out))
 
 
 def newcase_ekf(u, x, model: _Model, params: Params, s_init, Ps_init, s_final, Ps_final,

@@ -793,7 +793,11 @@ int orc_ekf_run(int model, int T, const double *u, const double *x, const orc_pa
             flip_cols(u_opt, nn, T); flip_cols(u_opt_smooth, nn, T);
             flip_cols(S_MINUS, m, T); flip_cols(S_PLUS, m, T); flip_cols(S_SMOOTH, m, T);
             flip_cols(P_MINUS, mm, T); flip_cols(P_PLUS, mm, T); flip_cols(P_SMOOTH, mm, T);
-            flip_cols(K_GAIN, m, T); flip_cols(innovations, 1, T); flip_cols(rho, 1, T);
+            flip_cols(K_GAIN, m, T); flip_cols(innovations, 1, T);
+            /* rho is NOT reversed.  GenericExtendedKalmanFilter.m:233 squeezes rho (1 x 1 x T) to a T x 1 column, and
+             * SIAlphaModelBackwardEKF.m:40 / ...BackwardEKFOptControlled.m:40 then index it `rho_flipped(:, :, end:-1:1)`:
+             * on a T x 1 array the third dimension has size 1, so `end` is 1 there and the expression returns the column
+             * as it stands -- rho(k) of the wrapper is the monitor value of FILTER step k, i.e. of caller day T+1-k. */
             if (pinv_rank)
                 for (int k = 0; k < T / 2; k++) { int t = pinv_rank[k]; pinv_rank[k] = pinv_rank[T - 1 - k]; pinv_rank[T - 1 - k] = t; }
         }

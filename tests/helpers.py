@@ -167,3 +167,15 @@ def make_regression_problem(S=40, D=120, n=12, seed=0):
     y = np.einsum("dns,ns->ds", X, a_true) + 0.08 + 0.004 * rng.standard_normal((D, S))
     y[:, 1::7] -= 0.2                                             # regions whose mean residual is negative
     return np.ascontiguousarray(X), np.ascontiguousarray(y)
+
+
+def lapack_reading_worker(job):
+    """Worker of a process pool (spawn context: the children never touch the GPU): chains `cs` of Workload `w` through
+    oracle/ekf_numpy.py -- the independent reading of the .m files that uses LAPACK's SVD for pinv, the closest thing to
+    MATLAB's own built-in available here.  Returns the quantities the HIP-vs-LAPACK report compares."""
+    w, cs = job
+    out = []
+    for c in cs:
+        nd = numpy_chain(w, int(c))
+        out.append({k: np.asarray(nd[k]) for k in ("S_MINUS", "S_PLUS", "S_SMOOTH", "u_opt_smooth", "pinv_rank")})
+    return out

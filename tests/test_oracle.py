@@ -123,6 +123,33 @@ def test_kat_backward_wrapper_is_unflip_of_generic():
     assert np.array_equal(o["S_MINUS"][-1, :, 1], w.s_final[:, 1])
 
 
+def test_kat_backward_wrapper_returns_rho_unreversed():
+    """MATLAB indexing rule behind SIAlphaModelBackwardEKF.m:40 / ...BackwardEKFOptControlled.m:40:
+    GenericExtendedKalmanFilter.m:233 returns rho = squeeze(zeros(1, 1, T)), a T x 1 column; the wrapper indexes it
+    `rho_flipped(:, :, end:-1:1)`.  In a three-subscript reference to a T x 1 array the third dimension has size 1, so
+    `end` evaluates to 1 and `1:-1:1` selects that single page: the column comes back UN-reversed.  Every other output
+    (m x T, m x m x T, m x 1 x T, 1 x T) is reversed by its own subscript.  Hence: wrapper rho == rho of the generic
+    filter run on the flipped inputs, in filter-step order -- and, since rho(1) == 0 (cc_1 = 0), the zero sits at
+    index 0, not at the end of the caller's time axis."""
+    from oracle import ekf_numpy as enp
+    for mk, m in ((lambda: synth.as_backward(synth.make_cfg3(2, 60)), 3),
+                  (lambda: synth.as_backward(synth.make_cfg4(1, 2, 40, 0)), 6)):
+        w = mk()
+        o = H.oracle_batch(w)
+        for c in range(w.B):
+            args = H.chain_args(w, c)
+            u, x, p, s_init, Pi, s_final, Pf = args[:7]
+            nd = H.numpy_chain(w, c)
+            # the generic filter on the flipped problem, no un-flip at all
+            plain = enp.generic_ekf(u[:, ::-1], x[::-1], enp.MODELS[w.model], p, s_final, Pf, s_init, Pi, *args[7:])
+            rho_plain, innov_plain = plain[10], plain[9]
+            assert np.array_equal(nd["rho"], rho_plain)                      # un-reversed
+            assert np.array_equal(nd["innovations"], innov_plain[::-1])      # 1 x T row: reversed
+            assert nd["rho"][0] == 0.0 and nd["rho"][-1] != 0.0
+            assert H.rel_err(o["rho"][:, c], nd["rho"]) <= 1e-9              # the C restatement follows the same rule
+            assert o["rho"][0, c] == 0.0
+
+
 def test_kat_mass_conservation_seirp():
     """(vi) SEIRP.m:27-31 right-hand sides sum to zero => s+e+i+r+p stays 1 under Euler."""
     from oracle import ekf_numpy as enp
