@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # EPIEKF_LIB: load another build of the same ABI instead (A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 
+ABI_VERSION = 2      # EPIEKF_ABI_VERSION of include/epiekf.h
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
@@ -35,7 +36,7 @@ class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "model", "B", "T", "Sx", "Su", "n_npi", "L", "order",
                                           "obs_type", "r_mode", "q_mode")] + [
         ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("chunks", C.c_int32),
-        ("lane_block", C.c_int32)]
+        ("lane_block", C.c_int32), ("shape", C.c_int32), ("storage", C.c_int32)]
 
 
 class Inputs(C.Structure):
@@ -174,7 +175,7 @@ def lib():
         h.epi_nnls_affine_fit_device.argtypes = [C.POINTER(NnlsDesc)] + [C.c_void_p] * 7 + [C.c_void_p, C.c_char_p]
         h.epi_calib_copy_f64_device.restype = C.c_int
         h.epi_calib_copy_f64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p]
-        if h.epi_abi_version() != 1:
+        if h.epi_abi_version() != ABI_VERSION:
             raise ImportError("libepiekf.so ABI version mismatch")
         _lib = h
     return _lib
@@ -189,7 +190,7 @@ def check(rc: int, err_buf) -> None:
 
 def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask, q_mode=0) -> BatchDesc:
     d = BatchDesc()
-    d.abi_version = 1
+    d.abi_version = ABI_VERSION
     d.model = L.MODEL_IDS[model] if isinstance(model, str) else int(model)
     d.B, d.T, d.Sx, d.Su, d.n_npi, d.L, d.order = int(B), int(T), int(Sx), int(Su), int(n_npi), int(L_), int(order)
     if isinstance(obs_type, str):
@@ -197,5 +198,5 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask,
     else:
         d.obs_type = int(obs_type)
     d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), int(q_mode), int(out_mask), 0
-    d.path_hint, d.chunks, d.lane_block = 0, 0, 0
+    d.path_hint, d.chunks, d.lane_block, d.shape, d.storage = 0, 0, 0, 0, 0
     return d

@@ -61,7 +61,7 @@ class DeviceWorkload:
 class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
-    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True, lane_block=0):
+    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True, lane_block=0, shape=0):
         """chunks > 1: a full run() is split into that many chain chunks on helper streams (overlaps the
         (chain, step)-parallel pinv grid with the sequential kernels of the other chunks).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
@@ -76,6 +76,8 @@ class EkfRunner:
         self.mask = out_mask_of(names)
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
                                    dw.r_mode, self.mask, dw.q_mode)
+        # epi_batch_desc.shape: 0 = by batch size, 1 = one lane per chain, 2 = four lanes per chain (6-state generic models)
+        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2}.get(shape, shape)
         if lane_block == "auto":       # one block per wavefront of the launch
             lane_block = int(_lib.lib().epi_ekf_preferred_lane_block(C.byref(self.desc)))
         self.blk = dw.B if (lane_block <= 0 or lane_block >= dw.B) else int(lane_block)
@@ -146,10 +148,10 @@ class EkfRunner:
         return sum(t.numel() * 8 for t in self.out.values())
 
 
-def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True, lane_block=0):
+def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True, lane_block=0, shape=0):
     """Convenience: upload `w`, run once, return dict name -> numpy array [T, rows, B] (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
-    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck, lane_block=lane_block)
+    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck, lane_block=lane_block, shape=shape)
     r.run()
     torch.cuda.synchronize(dw.device)
     res = {n: r.unblocked(n).cpu().numpy() for n in r.out}
@@ -200,7 +202,7 @@ def sialpha_sim(u, sp, z=None, u_series=None, with_cost=False, store=True, devic
     K, n_npi, Su = u.shape
     B = sp.shape[1]
     d = _lib.SimDesc()
-    d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, B, K, Su, n_npi
+    d.abi_version, d.B, d.K, d.Su, d.n_npi = _lib.ABI_VERSION, B, K, Su, n_npi
     d.noise, d.with_cost, d.prefix_days = int(z is not None), int(with_cost), 0
     out = {}
     if store:
@@ -231,7 +233,7 @@ def random_npi_mc(sp, u_min, n_scen, K, seed=0, z=None, J0_prefix=None, J1_prefi
     sp, u_min, z, J0p, J1p = t(sp), t(u_min), t(z), t(J0_prefix), t(J1_prefix)
     n_npi, R = u_min.shape
     d = _lib.McDesc()
-    d.abi_version, d.R, d.n_scen, d.K, d.n_npi = 1, R, int(n_scen), int(K), n_npi
+    d.abi_version, d.R, d.n_scen, d.K, d.n_npi = _lib.ABI_VERSION, R, int(n_scen), int(K), n_npi
     d.noise, d.prefix_days = int(z is not None), int(prefix_days)
     d.seed_lo, d.seed_hi = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
     out = {"J0": torch.empty((n_scen, R), dtype=torch.float64, device=dev),
@@ -323,7 +325,7 @@ def preprocess(cases, population, deaths=None, ip=None, W=7, min_cases=1.0, firs
     if ip is None and "ip_filled" in names:
         names.remove("ip_filled")
     d = _lib.PreDesc()
-    d.abi_version, d.S, d.T, d.n_npi = 1, S, T, 0 if ip is None else ip.shape[1]
+    d.abi_version, d.S, d.T, d.n_npi = _lib.ABI_VERSION, S, T, 0 if ip is None else ip.shape[1]
     d.W, d.first_num_days, d.min_cases = int(W), int(first_num_days), float(min_cases)
     out = {}
     for n in names:
@@ -352,7 +354,7 @@ def nnls_affine_fit(X, y, max_iters=100, device="cuda:0"):
     X, y = t(X).contiguous(), t(y).contiguous()
     D, n, S = X.shape
     d = _lib.NnlsDesc()
-    d.abi_version, d.S, d.D, d.n, d.max_iters = 1, S, D, n, int(max_iters)
+    d.abi_version, d.S, d.D, d.n, d.max_iters = _lib.ABI_VERSION, S, D, n, int(max_iters)
     out = {"a": torch.empty((n, S), dtype=torch.float64, device=dev), "b": torch.empty((S,), dtype=torch.float64, device=dev),
            "min_err": torch.empty((S,), dtype=torch.float64, device=dev),
            "iters": torch.empty((S,), dtype=torch.int32, device=dev), "flag": torch.empty((S,), dtype=torch.int32, device=dev)}
@@ -386,7 +388,7 @@ class RtRunner:
         self.out = {n: torch.empty((w.T, w.B) if RT_OUT_ROWS[n] == 0 else (w.T, RT_OUT_ROWS[n], w.B), dtype=torch.float64,
                                    device=dev) for n in names}
         self.desc = _lib.RtDesc()
-        self.desc.abi_version, self.desc.B, self.desc.T, self.desc.Sx = 1, w.B, w.T, w.x.shape[1]
+        self.desc.abi_version, self.desc.B, self.desc.T, self.desc.Sx = _lib.ABI_VERSION, w.B, w.T, w.x.shape[1]
         self.desc.L, self.desc.order = int(w.L), int(w.order)
         self.outs = _lib.RtOutputs()
         for n in _lib.RT_OUT_NAMES:
@@ -449,7 +451,7 @@ def score_sweep(u_opt_smooth, t_hist, sp, J0_prefix, J1_prefix, store=False, B=N
     sp, J0p, J1p = t(sp), t(J0_prefix), t(J1_prefix)
     u_h = u_opt_smooth[t_hist:]                 # contiguous view: [H, n_npi, B]
     d = _lib.SimDesc()
-    d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, B, H, B, n_npi
+    d.abi_version, d.B, d.K, d.Su, d.n_npi = _lib.ABI_VERSION, B, H, B, n_npi
     d.noise, d.with_cost, d.prefix_days, d.u_block = 0, 1, int(t_hist), int(u_block)
     out = {"J0": torch.empty((B,), dtype=torch.float64, device=dev), "J1": torch.empty((B,), dtype=torch.float64, device=dev)}
     if store:

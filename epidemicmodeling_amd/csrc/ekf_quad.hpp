@@ -1,0 +1,571 @@
+// ekf_quad.hpp -- cooperative forward / backward kernels: FOUR lanes per chain (6-state generic models).
+// Included from epiekf.hip inside namespace epi, after ekf_sym.hpp.
+//
+// Why a second shape.  With one lane per chain (ekf_sym.hpp) a wavefront carries ~1500 (forward) / ~1300 (backward)
+// dependent fp64 instructions per day and needs 300-410 VGPRs, i.e. one wave per SIMD: a batch that does not fill the
+// chip (the 9 375-chain shard of the headline sweep on one of 8 GPUs = 147 waves for 1024 SIMDs) runs at the latency
+// of a lone wave, ~5 us per day.  Here the four lanes of a DPP quad share one chain: every 6 x 6 matrix is cut into a
+// 2 x 2 grid of 3 x 3 blocks and lane (bi, bj) = (quad lane >> 1, quad lane & 1) owns block (bi, bj), so a matrix
+// product costs each lane 54 instead of 216 fma, the blocks it needs from its neighbours arrive by `v_mov_b32_dpp
+// quad_perm` (two per double, no LDS), and a wavefront holds 16 chains in a quarter of the registers.  Four times as
+// many waves per batch, a per-day instruction stream ~2x shorter: what a small batch needs.  At 75 000 chains the chip
+// is full either way and the one-lane-per-chain kernels do less total work; the host picks the shape by batch size
+// (epi_batch_desc.shape).
+//
+// Arithmetic: every output element is produced by the same sequence of roundings as in ekf_sym.hpp / the oracle -- a
+// reduction is per element, and an element's whole fma chain (k ascending) runs in ONE lane; where a chain spans two
+// blocks (the smoother's J * (s - s^-)) the partial sum is handed from the left lane to the right lane and continued.
+// Products with structural zeros of the Jacobian are NOT skipped here (the union of the two block rows' patterns is
+// nearly dense): fma(0, x, acc) == acc for finite operands, the same caveat as in ekf_sym.hpp.
+#pragma once
+
+constexpr int kQC = kWave / 4;   // chains per wavefront
+
+#define EPI_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+constexpr int QP_ROW_L = EPI_QP(0, 0, 2, 2);   // block (bi, 0) of my block row
+constexpr int QP_ROW_R = EPI_QP(1, 1, 3, 3);   // block (bi, 1)
+constexpr int QP_COL_T = EPI_QP(0, 1, 0, 1);   // block (0, bj) of my block column
+constexpr int QP_COL_B = EPI_QP(2, 3, 2, 3);   // block (1, bj)
+constexpr int QP_TRN = EPI_QP(0, 2, 1, 3);     // lane (bj, bi): the transposed position
+constexpr int QP_CJ_L = EPI_QP(0, 2, 0, 2);    // block (bj, 0): block row bj, left
+constexpr int QP_CJ_R = EPI_QP(1, 3, 1, 3);    // block (bj, 1)
+
+template <int CTRL>
+EPI_DEV double qx(double v)
+{
+    const u32x2 w = __builtin_bit_cast(u32x2, v);
+    u32x2 r;
+    r.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w.x, CTRL, 0xf, 0xf, true);
+    r.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w.y, CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, r);
+}
+typedef double blk3[3][3];
+template <int CTRL>
+EPI_DEV void qx3(const blk3 &s, blk3 &d)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) d[r][c] = qx<CTRL>(s[r][c]);
+}
+// d = (block held by the transposed lane)' : d[r][c] is element (j, i) of the matrix when mine is (i, j)
+EPI_DEV void qx3_transposed(const blk3 &s, blk3 &d)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) d[r][c] = qx<QP_TRN>(s[c][r]);
+}
+EPI_DEV void qsym(const blk3 &F, blk3 &P)      // (F + F')/2.0   GenericEKF.m:138,161,226
+{
+    blk3 Ft;
+    qx3_transposed(F, Ft);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) P[r][c] = (F[r][c] + Ft[r][c]) / 2.0;
+}
+
+struct Quad {
+    int q, lc;          // lane in the quad, chain in the wavefront
+    bool bi, bj;        // block row / block column owned
+    unsigned cpart;     // byte offset of this chain inside a time slice of a 36-row array, + my block's first row
+};
+
+// --- addressing of the chain-blocked arrays (see Lay): element (row e, chain c) of slice t -------------------------
+// vector arrays (6 rows): quad lane q holds rows q and q + 4
+EPI_DEV void qstore_vec(double *__restrict__ dst, int t, const Lay &l, const Quad &Q, const double (&v)[6])
+{
+    if (!dst) return;
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(dst, t, 6, l, voff, rowb);
+    const double lo = (Q.q == 0) ? v[0] : (Q.q == 1) ? v[1] : (Q.q == 2) ? v[2] : v[3];
+    const double hi = (Q.q & 1) ? v[5] : v[4];
+    bst(r, voff + (unsigned)Q.q * rowb, 0u, lo);
+    if (Q.q < 2) bst(r, voff + (unsigned)Q.q * rowb, 4u * rowb, hi);
+}
+EPI_DEV void qload_vec(const double *__restrict__ src, int t, const Lay &l, double (&v)[6])
+{
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(src, t, 6, l, voff, rowb);
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = bld(r, voff, (unsigned)i * rowb);
+}
+// my 3 x 3 block of a 6 x 6 array stored with all 36 rows (row e = i + 6 j).  upper_only: entries below the diagonal
+// are not written (workspace that is only read back through qload_sym_blk / eks_pinv)
+EPI_DEV void qstore_blk(double *__restrict__ dst, int t, const Lay &l, const Quad &Q, const blk3 &Bk, bool upper_only)
+{
+    if (!dst) return;
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(dst, t, 36, l, voff, rowb);
+    const unsigned vo = voff + (unsigned)((Q.bi ? 3 : 0) + (Q.bj ? 18 : 0)) * rowb;
+    const bool le = !(Q.bi && !Q.bj), lt = (!Q.bi && Q.bj);     // block row <= / < block column
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            const bool ok = !upper_only || (rr <= c ? le : lt);
+            if (ok) bst(r, vo, (unsigned)(rr + 6 * c) * rowb, Bk[rr][c]);
+        }
+}
+// my block of a SYMMETRIC 6 x 6 array of which only the upper triangle may be stored: element (i, j) is read from
+// row min + 6 max.  rows36 = false: the packed 21-row form (row i + j (j + 1) / 2, i <= j) of eks_pinv's X.
+struct QOff { unsigned o[3][3]; };
+EPI_DEV QOff qoffsets(const Quad &Q, unsigned rowb, bool rows36)
+{
+    QOff f;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + c;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            f.o[r][c] = (unsigned)(rows36 ? lo + 6 * hi : lo + hi * (hi + 1) / 2) * rowb;
+        }
+    return f;
+}
+EPI_DEV void qload_sym_blk(const double *__restrict__ src, int t, const Lay &l, const QOff &f, unsigned rows, blk3 &Bk)
+{
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice(src, t, rows, l, voff, rowb);
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) Bk[rr][c] = bld(r, voff + f.o[rr][c], 0u);
+}
+
+// rows of the Jacobian a lane multiplies with: its block row's (bi) and its block column's (bj)
+EPI_DEV void qrows(const double (&A)[36], bool hi, double (&R)[3][6])
+{
+    constexpr int M = 6;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) R[r][k] = hi ? A[IXM(3 + r, k)] : A[IXM(r, k)];
+}
+// C(i, j) = sum_k L(i, k) * Rr(j, k), k = 0..5 ascending, for my block: Lfull = [Ll | Lr] holds rows i (all six
+// columns), Rr[c][k] row j = 3 bj + c of the right factor
+EPI_DEV void qmul_bt(const blk3 &Ll, const blk3 &Lr, const double (&Rr)[3][6], blk3 &Cb)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double acc = Ll[r][0] * Rr[c][0];
+            acc = fma(Ll[r][1], Rr[c][1], acc);
+            acc = fma(Ll[r][2], Rr[c][2], acc);
+            acc = fma(Lr[r][0], Rr[c][3], acc);
+            acc = fma(Lr[r][1], Rr[c][4], acc);
+            acc = fma(Lr[r][2], Rr[c][5], acc);
+            Cb[r][c] = acc;
+        }
+}
+// C(i, j) = sum_k Lr(i, k) * R(k, j): Lrow[r][k] row i = 3 bi + r of the left factor (all six columns),
+// R = [Rt ; Rb] column block bj (all six rows)
+EPI_DEV void qmul_rows(const double (&Lrow)[3][6], const blk3 &Rt, const blk3 &Rb, blk3 &Cb)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double acc = Lrow[r][0] * Rt[0][c];
+            acc = fma(Lrow[r][1], Rt[1][c], acc);
+            acc = fma(Lrow[r][2], Rt[2][c], acc);
+            acc = fma(Lrow[r][3], Rb[0][c], acc);
+            acc = fma(Lrow[r][4], Rb[1][c], acc);
+            acc = fma(Lrow[r][5], Rb[2][c], acc);
+            Cb[r][c] = acc;
+        }
+}
+// C = L * R with both factors held as blocks: L(i, :) = [Ll | Lr], R(:, j) = [Rt ; Rb]
+EPI_DEV void qmul(const blk3 &Ll, const blk3 &Lr, const blk3 &Rt, const blk3 &Rb, blk3 &Cb)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            double acc = Ll[r][0] * Rt[0][c];
+            acc = fma(Ll[r][1], Rt[1][c], acc);
+            acc = fma(Ll[r][2], Rt[2][c], acc);
+            acc = fma(Lr[r][0], Rb[0][c], acc);
+            acc = fma(Lr[r][1], Rb[1][c], acc);
+            acc = fma(Lr[r][2], Rb[2][c], acc);
+            Cb[r][c] = acc;
+        }
+}
+
+// P(k+1|k) = sym(A P(k|k) A' + Q), Q diagonal (GenericEKF.m:158-161): blocks in, blocks out (cf. predict_cov_sym)
+EPI_DEV void qpredict_cov(const Quad &Q, const double (&A)[36], const blk3 &Pp, const double (&Qd)[6], blk3 &Pm)
+{
+    double Ar[3][6], Ac[3][6];
+    qrows(A, Q.bi, Ar);
+    qrows(A, Q.bj, Ac);
+    blk3 Pt, Pb, T1, T1l, T1r, G;
+    qx3<QP_COL_T>(Pp, Pt);
+    qx3<QP_COL_B>(Pp, Pb);
+    qmul_rows(Ar, Pt, Pb, T1);                 // T1 = A P
+    qx3<QP_ROW_L>(T1, T1l);
+    qx3<QP_ROW_R>(T1, T1r);
+    qmul_bt(T1l, T1r, Ac, G);                  // G = T1 A'
+    const bool dg = (Q.bi == Q.bj);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double qv = (r == c && dg) ? (Q.bi ? Qd[3 + r] : Qd[r]) : 0.0;
+            G[r][c] = G[r][c] + qv;
+        }
+    qsym(G, Pm);
+}
+
+// ---------------------------------------------------------------------------
+// forward pass
+// ---------------------------------------------------------------------------
+template <int FLIP>
+__global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *__restrict__ dense_flag)
+{
+    constexpr int M = 6;
+    extern __shared__ double lds[];   // windows [3][L][kQC] + model vectors [48][kQC], one column per chain
+    if (*dense_flag) return;
+    Quad Q;
+    Q.q = threadIdx.x & 3; Q.lc = threadIdx.x >> 2; Q.bi = (Q.q >> 1) != 0; Q.bj = (Q.q & 1) != 0;
+    const int c = a.c0 + blockIdx.x * kQC + Q.lc;
+    if (c >= a.c0 + a.cn) return;               // whole quads leave together
+    const int B = a.B, T = a.T, L = a.L;
+    const int sx = a.x_series ? a.x_series[c] : c;
+    const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    constexpr int stride = kQC;
+    LitePrm<VecLdsS> p;
+    init_prm<M>(p, a, B, c, lds + (size_t)3 * L * stride + Q.lc, stride);   // (the four lanes write the same values)
+    const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
+    const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
+    const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
+
+    double sk_minus[M], Qd[M];
+    blk3 Pm;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        sk_minus[i] = a.s_init[(size_t)i * B + c];
+        Qd[i] = a.Q[(size_t)IXM(i, i) * B + c];
+    }
+    // Ps_init is bit-wise symmetric (ekf_precheck); the packed kernel reads its upper triangle, so do we
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + cc;
+            Pm[r][cc] = a.Ps_init[(size_t)(i < j ? IXM(i, j) : IXM(j, i)) * B + c];
+        }
+
+    double *winMean = lds + Q.lc, *winCov = lds + (size_t)L * stride + Q.lc, *winCovN = lds + (size_t)2 * L * stride + Q.lc;
+    for (int j = 0; j < L; j++) { winMean[j * stride] = 0.0; winCov[j * stride] = 0.0; winCovN[j * stride] = 0.0; }
+    int head = 0;
+    const bool fixed_R = (a.r_mode == 0);
+    const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
+    double R_next = R_v;
+
+    const unsigned voff_x = (unsigned)sx * 8u;
+    double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(0, T) * a.Sx, voff_x);
+    double r_nxt = fixed_R ? 0.0 : ldg(a.R_series, voff_x);
+    double u_nxt[kNpi];
+    load_u(a, tpos<FLIP>(0, T), su, u_nxt);
+
+    for (int k = 0; k < T; k++) {
+        const int t = tpos<FLIP>(k, T);
+        const double Rk = fixed_R ? R_next : r_nxt;
+        const double xk = x_nxt;
+        double u_in[kNpi];
+#pragma unroll
+        for (int qq = 0; qq < kNpi; qq++) u_in[qq] = u_nxt[qq];
+        if (k + 1 < T) {
+            const int tn = tpos<FLIP>(k + 1, T);
+            x_nxt = ldg(a.x + (size_t)tn * a.Sx, voff_x);
+            if (!fixed_R) r_nxt = ldg(a.R_series + (size_t)(k + 1) * a.Sx, voff_x);
+            load_u(a, tn, su, u_nxt);
+        }
+
+        qstore_vec(a.S_MINUS, t, lay, Q, sk_minus);
+        qstore_blk(a.P_MINUS, t, lay, Q, Pm, (a.ws_upper & 1) != 0);
+
+        double C[M];
+        obs_jacobian<M>(a.mf, sk_minus, C);                 // C(4:6) == 0
+        const double xk_minus = predict_obs<M>(a.mf, sk_minus, v_bar);
+
+        double innov, K[M], sk_plus[M];
+        blk3 Pp;
+        const bool valid = !is_nan(xk);
+        if (valid) {
+            innov = xk - xk_minus;
+            // P C' for my block row: formed by the lane that owns block (bi, 0) -- C(4:6) = 0 -- and handed to the right
+            double PCr[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                double acc = Pm[r][0] * C[0];
+                acc = fma(Pm[r][1], C[1], acc);
+                acc = fma(Pm[r][2], C[2], acc);
+                PCr[r] = qx<QP_ROW_L>(acc);
+            }
+            double PC0[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) PC0[r] = qx<EPI_QP(0, 0, 0, 0)>(PCr[r]);
+            double CPCt = PC0[0] * C[0];
+            CPCt = fma(PC0[1], C[1], CPCt);
+            CPCt = fma(PC0[2], C[2], CPCt);
+            const double den = CPCt + gamma * Rk;
+            double Kr[3], Kc[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) Kr[r] = PCr[r] / den;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                K[r] = qx<EPI_QP(0, 0, 0, 0)>(Kr[r]);
+                K[3 + r] = qx<EPI_QP(2, 2, 2, 2)>(Kr[r]);
+                Kc[r] = Q.bj ? K[3 + r] : K[r];
+            }
+            // (I - K C): my block row's and my block column's rows of its first three columns
+            double IKr[3][3], IKc[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    IKr[r][j] = ((r == j && !Q.bi) ? 1.0 : 0.0) - Kr[r] * C[j];
+                    IKc[r][j] = ((r == j && !Q.bj) ? 1.0 : 0.0) - Kc[r] * C[j];
+                }
+            // Joseph form :127, cf. ekf_fwd_sym: T1 = (I - K C) P, F = (T1 (I - K C)' + K R K') / gamma
+            blk3 P0, T1, T1l, F;
+            qx3<QP_COL_T>(Pm, P0);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) {
+                    double acc = IKr[r][0] * P0[0][cc];
+                    acc = fma(IKr[r][1], P0[1][cc], acc);
+                    acc = fma(IKr[r][2], P0[2][cc], acc);
+                    const double plus = acc + Pm[r][cc];            // + 1 * P(i, j) for i >= 3
+                    T1[r][cc] = Q.bi ? plus : acc;
+                }
+            qx3<QP_ROW_L>(T1, T1l);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) {
+                    double acc = T1l[r][0] * IKc[cc][0];
+                    acc = fma(T1l[r][1], IKc[cc][1], acc);
+                    acc = fma(T1l[r][2], IKc[cc][2], acc);
+                    const double plus = acc + T1[r][cc];            // + T1(i, j) for j >= 3
+                    acc = Q.bj ? plus : acc;
+                    F[r][cc] = (acc + (Kr[r] * Rk) * Kc[cc]) / gamma;
+                }
+            qsym(F, Pp);
+#pragma unroll
+            for (int i = 0; i < M; i++) sk_plus[i] = sk_minus[i] + K[i] * innov;
+        } else {
+            innov = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) { K[i] = 0.0; sk_plus[i] = sk_minus[i]; }
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) Pp[r][cc] = Pm[r][cc];
+        }
+        state_hard_margins<M>(p, sk_plus);
+
+        double u_app[kNpi];
+#pragma unroll
+        for (int qq = 0; qq < kNpi; qq++) u_app[qq] = u_in[qq];
+        nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
+        if (Q.q == 0) store_u(a.u_opt, a, t, lay, u_app);
+        {
+            double A[M * M];
+            state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
+            qpredict_cov(Q, A, Pp, Qd, Pm);
+        }
+        state_hard_margins<M>(p, sk_minus);
+
+        qstore_vec(a.S_PLUS, t, lay, Q, sk_plus);
+        qstore_blk(a.P_PLUS, t, lay, Q, Pp, (a.ws_upper & 2) != 0);
+        qstore_vec(a.K_GAIN, t, lay, Q, K);
+        if (a.innovations && Q.q == 0) a.innovations[lay_scalar(t, lay)] = innov;
+
+        // innovation monitor (identical to ekf_fwd_sym; the four lanes of a quad compute the same numbers)
+        const int cnt = (k + 1 < L) ? (k + 1) : L;
+        head = (head == 0) ? (L - 1) : (head - 1);
+        winMean[head * stride] = innov;
+        const double sum = ring_sum(winMean, head, L, innov, stride);
+        const double mu = sum / (double)cnt;
+        const double cc2 = (innov - mu) * (innov - mu);
+        const double ccn = cc2 / (Rk + kEps);
+        winCov[head * stride] = cc2;
+        winCovN[head * stride] = ccn;
+        const double sumN = ring_sum(winCovN, head, L, ccn, stride);
+        if (a.rho && Q.q == 0) a.rho[lay_scalar(k, lay)] = sumN / (double)cnt;   // filter-step order (see ekf_fwd_sym)
+        if (fixed_R) {
+            if (beta != 1.0 && valid && k < T - 1) {
+                const double sumC = ring_sum(winCov, head, L, cc2, stride);
+                R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);
+            } else {
+                R_next = R_v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward recursion (X = pinv(P_MINUS) comes from eks_pinv, packed)
+// ---------------------------------------------------------------------------
+template <int FLIP>
+__global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *__restrict__ dense_flag)
+{
+    constexpr int M = 6;
+    __shared__ double vlds[4 * kNpi * kQC];
+    if (*dense_flag) return;
+    Quad Q;
+    Q.q = threadIdx.x & 3; Q.lc = threadIdx.x >> 2; Q.bi = (Q.q >> 1) != 0; Q.bj = (Q.q & 1) != 0;
+    const int c = a.c0 + blockIdx.x * kQC + Q.lc;
+    if (c >= a.c0 + a.cn) return;
+    const int B = a.B, T = a.T;
+    const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    LitePrm<VecLdsS> p;
+    init_prm<M>(p, a, B, c, vlds + Q.lc, kQC);
+    const unsigned rowb = lay.blk * 8u;
+    const QOff o36 = qoffsets(Q, rowb, true), o21 = qoffsets(Q, rowb, false);
+
+    // terminal conditions GenericEKF.m:189-202 (Ps_final symmetric in values and NaN pattern: ekf_precheck)
+    double Ss[M];
+    blk3 Ps;
+    const int tT = tpos<FLIP>(T - 1, T);
+    qload_vec(a.S_PLUS, tT, lay, Ss);
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const double f = a.s_final[(size_t)i * B + c];
+        if (!is_nan(f)) Ss[i] = f;
+    }
+    qload_sym_blk(a.P_PLUS, tT, lay, o36, 36, Ps);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + cc;
+            const double f = a.Ps_final[(size_t)(i < j ? IXM(i, j) : IXM(j, i)) * B + c];
+            if (!is_nan(f)) Ps[r][cc] = f;
+        }
+    qstore_vec(a.S_SMOOTH, tT, lay, Q, Ss);
+    qstore_blk(a.P_SMOOTH, tT, lay, Q, Ps, false);
+    if (a.u_opt_smooth && Q.q == 0) {
+        double z[kNpi];
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) z[k] = 0.0;
+        store_u(a.u_opt_smooth, a, tT, lay, z);
+    }
+    if (a.pinv_rank && Q.q == 0) a.pinv_rank[lay_scalar(tT, lay)] = -1;
+
+    int st_guard = 0, st_cap = 0, min_rank = M;
+    for (int k = T - 2; k >= 0; k--) {
+        const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
+        double Sp[M], Sm1[M], u_in[kNpi];
+        blk3 Pp, X, Pm1;
+        qload_vec(a.S_PLUS, t, lay, Sp);
+        load_u(a, t, su, u_in);
+        const int rk = a.rankbuf[lay_scalar(t1, lay)];
+        qload_sym_blk(a.P_PLUS, t, lay, o36, 36, Pp);
+        qload_sym_blk(a.X, t1, lay, o21, 21, X);             // (garbage where the :211 guard fired, rk < 0: unused)
+        qload_vec(a.S_MINUS, t1, lay, Sm1);
+        qload_sym_blk(a.P_MINUS, t1, lay, o36, 36, Pm1);
+
+        double A[M * M];
+        state_jacobians<M, FLIP>(p, u_in, Sp, A);              // :206
+        blk3 J;
+        int rank = -1;
+        if (rk < 0) {                                          // non-finite P_MINUS guard :211-213
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) J[r][cc] = 0.0;
+            st_guard = 1;
+        } else {
+            // J = (P+ A') X  :215
+            double Ac[3][6];
+            qrows(A, Q.bj, Ac);
+            blk3 Pl, Pr, PA, PAl, PAr, Xt, Xb;
+            qx3<QP_ROW_L>(Pp, Pl);
+            qx3<QP_ROW_R>(Pp, Pr);
+            qmul_bt(Pl, Pr, Ac, PA);
+            qx3<QP_ROW_L>(PA, PAl);
+            qx3<QP_ROW_R>(PA, PAr);
+            qx3<QP_COL_T>(X, Xt);
+            qx3<QP_COL_B>(X, Xb);
+            qmul(PAl, PAr, Xt, Xb, J);
+            rank = rk & 0xff;
+            st_cap |= (rk >> 8) & 1;
+            min_rank = rank < min_rank ? rank : min_rank;
+        }
+        // S_SMOOTH(k) = clamp(s+ + J (s_s(k+1) - s-(k+1)))  :218-221.  The chain over j = 0..5 of row i starts in the
+        // lane that owns J(i, 0:2) and is continued by the lane that owns J(i, 3:5)
+        double Sn[M];
+        {
+            double dv[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) dv[i] = Ss[i] - Sm1[i];
+            double accr[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                double accl = J[r][0] * dv[0];
+                accl = fma(J[r][1], dv[1], accl);
+                accl = fma(J[r][2], dv[2], accl);
+                const double from_left = qx<QP_ROW_L>(accl);
+                double acc = fma(J[r][0], dv[3], from_left);
+                acc = fma(J[r][1], dv[4], acc);
+                acc = fma(J[r][2], dv[5], acc);
+                accr[r] = acc;                                 // complete in the lanes with bj = 1
+            }
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                Sn[r] = Sp[r] + qx<EPI_QP(1, 1, 1, 1)>(accr[r]);
+                Sn[3 + r] = Sp[3 + r] + qx<EPI_QP(3, 3, 3, 3)>(accr[r]);
+            }
+        }
+        state_hard_margins<M>(p, Sn);
+        {
+            // P_SMOOTH(k) = sym(P+ - (J D) J'),  D = P_MINUS(k+1) - P_SMOOTH(k+1)   :223-226
+            blk3 D, Jl, Jr, Dt, Db, T1, T1l, T1r, Jcl, Jcr, F;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) D[r][cc] = Pm1[r][cc] - Ps[r][cc];
+            qx3<QP_ROW_L>(J, Jl);
+            qx3<QP_ROW_R>(J, Jr);
+            qx3<QP_COL_T>(D, Dt);
+            qx3<QP_COL_B>(D, Db);
+            qmul(Jl, Jr, Dt, Db, T1);
+            qx3<QP_ROW_L>(T1, T1l);
+            qx3<QP_ROW_R>(T1, T1r);
+            qx3<QP_CJ_L>(J, Jcl);
+            qx3<QP_CJ_R>(J, Jcr);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int cc = 0; cc < 3; cc++) {
+                    double acc = T1l[r][0] * Jcl[cc][0];
+                    acc = fma(T1l[r][1], Jcl[cc][1], acc);
+                    acc = fma(T1l[r][2], Jcl[cc][2], acc);
+                    acc = fma(T1r[r][0], Jcr[cc][0], acc);
+                    acc = fma(T1r[r][1], Jcr[cc][1], acc);
+                    acc = fma(T1r[r][2], Jcr[cc][2], acc);
+                    F[r][cc] = Pp[r][cc] - acc;
+                }
+            qsym(F, Ps);
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) Ss[i] = Sn[i];
+        if (a.pinv_rank && Q.q == 0) a.pinv_rank[lay_scalar(t, lay)] = rank;
+        qstore_vec(a.S_SMOOTH, t, lay, Q, Ss);
+        qstore_blk(a.P_SMOOTH, t, lay, Q, Ps, false);
+        if (a.u_opt_smooth) {                                  // :229
+            double sn_unused[M];
+            nlin_state_update<M, FLIP>(p, a.mf, u_in, Ss, sn_unused);
+            if (Q.q == 0) store_u(a.u_opt_smooth, a, t, lay, u_in);
+        }
+    }
+    if (a.status && Q.q == 0) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+}

@@ -59,6 +59,7 @@ struct KArgs {
     // the host narrows the waves so that the rounds are equally full (launch_chain): the sequential kernels are
     // bound by HBM / per-CU memory throughput, which scales with active lanes, not by wave count.
     int lw;
+    int quad;   // 6-state generic models: four lanes per chain (ekf_quad.hpp) instead of one
 };
 
 // position in the caller's time axis of filter step k (flipped wrappers run the
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 }
 
 #include "ekf_sym.hpp"
+#include "ekf_quad.hpp"
 
 // ---------------------------------------------------------------------------
 // forward simulators
@@ -864,6 +866,31 @@ static int balanced_lanes(int cn, int waves_per_simd)
     return (int)(lw > kWave ? kWave : lw);
 }
 
+// Which lane mapping runs the 6-state generic models (epi_batch_desc.shape).  Auto: four lanes per chain while the
+// batch leaves SIMDs without a one-lane-per-chain wave of their own -- then the chains' per-day latency is what
+// counts, and the quad kernels' instruction stream is half as long; one lane per chain (least total work) once every
+// SIMD has one.  Crossover measured on the headline sweep's shards, profiles/r02/batch_size_sweep.txt.
+// EPIEKF_SHAPE=1|2 overrides (measurement).
+static int g_simd_count = 0;
+static int simd_count()
+{
+    if (!g_simd_count) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        g_simd_count = cus * 4;
+    }
+    return g_simd_count;
+}
+static bool use_quad(int shape, int m, bool generic, int B)
+{
+    if (m != 6 || !generic) return false;
+    if (const char *env = getenv("EPIEKF_SHAPE")) { const int v = atoi(env); if (v == 1 || v == 2) shape = v; }
+    if (shape == EPI_SHAPE_QUAD) return true;
+    if (shape == EPI_SHAPE_LANE) return false;
+    return (long)B <= (long)simd_count() * kWave / 2;
+}
+
 // phase: 0 = everything; 1 = forward kernel; 2 = smoother (pinv + backward); 3 = pinv kernel; 4 = backward kernel
 template <int M, int FLIP, int GENERIC>
 static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth, int hint, size_t shmem, hipStream_t st)
@@ -873,6 +900,35 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
     const int blocks = (cn + ka.lw - 1) / ka.lw;
     const bool run_sym = GENERIC && hint != 2, run_dense = !GENERIC || hint != 1;
     hipError_t e = hipSuccess;
+    if constexpr (M == 6 && GENERIC) {
+        if (ka.quad && run_sym) {
+            // four lanes per chain: 16 chains per wavefront (ekf_quad.hpp); the dense fall-back keeps its own mapping
+            const int qblocks = (cn + kQC - 1) / kQC;
+            if (phase == 0 || phase == 1) {
+                const size_t qshm = ((size_t)3 * ka.L + 4 * kNpi) * kQC * sizeof(double);
+                hipLaunchKernelGGL((ekf_fwd_quad<FLIP>), dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if (run_dense) {
+                    hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                }
+            }
+            if (!smooth) return e;
+            if (ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
+                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, st, ka);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
+            if (phase == 0 || phase == 2 || phase == 4) {
+                hipLaunchKernelGGL((eks_bwd_quad<FLIP>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if (run_dense) {
+                    hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
+                    e = hipGetLastError();
+                }
+            }
+            return e;
+        }
+    }
     if (phase == 0 || phase == 1) {
         if (run_sym) {   // hint 0: both variants are enqueued, the one ekf_precheck did not select returns at once
             // narrow (balanced) waves: the variant with LDS-resident model constants and LDS sized by 40 lanes -- 298
@@ -957,7 +1013,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
         }
         return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
     }
-    if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1) {
+    if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1 && !ka.quad) {
         // Pipelined halves.  The forward kernel of the second half and the eks_pinv grid of the first half are in flight
         // together, and -- because this forward variant (LDS-resident model constants, LDS sized by the lanes used)
         // needs 298 VGPRs and eks_pinv 168 -- they share SIMDs: the VALU-bound Jacobi runs in the issue slots the
@@ -1066,6 +1122,8 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
     if (d->chunks < -2) { set_err(err, "chunks must be >= -2"); return EPI_ERR_BAD_ARG; }
     if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
+    if (d->shape < 0 || d->shape > 2) { set_err(err, "shape must be 0 (auto), 1 (lane per chain) or 2 (quad per chain)"); return EPI_ERR_BAD_ARG; }
+    if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
@@ -1083,7 +1141,8 @@ int epi_ekf_preferred_lane_block(const epi_batch_desc *d)
     if (!d) return 0;
     probe = *d; probe.lane_block = 0;
     if (epi_ekf_validate(&probe, nullptr) != EPI_OK) return 0;
-    const int lw = balanced_lanes(d->B, MODEL_TABLE[d->model].m == 6 ? 1 : 2);
+    const ModelInfo &mi = MODEL_TABLE[d->model];
+    const int lw = use_quad(d->shape, mi.m, mi.generic != 0, d->B) ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2);
     return lw < d->B ? lw : d->B;
 }
 
@@ -1111,6 +1170,7 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     KArgs ka{};
     ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode; ka.q_mode = d->q_mode;
     ka.blk = lane_block_of(d); ka.nblk = (d->B + ka.blk - 1) / ka.blk;
+    ka.quad = use_quad(d->shape, mi.m, mi.generic != 0, d->B) ? 1 : 0;
     ka.mf.lo_is_zero = mi.lo_is_zero; ka.mf.phi_ge = mi.phi_ge; ka.mf.obs_clamp = mi.obs_clamp;
     ka.mf.obs_type = mi.obs_fixed ? EPI_OBS_NEWCASES : d->obs_type;
     ka.x_series = in->x_series; ka.u_series = in->u_series;

@@ -257,7 +257,7 @@ def Rt_ExpFitEKF(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma
     rp[11:15, 0] = np.asarray(Ps_init, dtype=np.float64).reshape(2, 2).reshape(-1, order="F")
     rp[15:19, 0] = np.asarray(Q_w, dtype=np.float64).reshape(2, 2).reshape(-1, order="F")
     d = _lib.RtDesc()
-    d.abi_version, d.B, d.T, d.Sx, d.L, d.order = 1, 1, T, 1, int(inv_monitor_len), int(order)
+    d.abi_version, d.B, d.T, d.Sx, d.L, d.order = _lib.ABI_VERSION, 1, T, 1, int(inv_monitor_len), int(order)
     rows = {"S_MINUS": 2, "S_PLUS": 2, "P_MINUS": 4, "P_PLUS": 4, "K_GAIN": 2, "S_SMOOTH": 2, "P_SMOOTH": 4,
             "innovations": 1, "rho": 1}
     out = {n: np.zeros((T, r, 1)) for n, r in rows.items()}
@@ -347,7 +347,7 @@ def SIalpha_Controlled(u, s0, i0, alpha0, u_max, alpha_min, alpha_max, gamma, a,
     zz = None if z is None else np.ascontiguousarray(z.T)                 # [K][3][1]
     uu = np.ascontiguousarray(u[:, :K].T)                                 # [K][n_npi][1]
     d = _lib.SimDesc()
-    d.abi_version, d.B, d.K, d.Su, d.n_npi, d.noise = 1, 1, K, 1, n, int(zz is not None)
+    d.abi_version, d.B, d.K, d.Su, d.n_npi, d.noise = _lib.ABI_VERSION, 1, K, 1, n, int(zz is not None)
     out = [np.zeros((1, K)) for _ in range(3)]
     err = C.create_string_buffer(256)
     rc = _lib.lib().epi_sialpha_sim_host(C.byref(d), None, _vp(uu), _vp(sp), _vp(zz), _vp(out[0]), _vp(out[1]), _vp(out[2]),

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define EPIEKF_ABI_VERSION 1
+#define EPIEKF_ABI_VERSION 2
 
 /* which reference function the chain runs */
 typedef enum epi_model {
@@ -133,7 +133,19 @@ typedef struct epi_batch_desc {
                              to see from ~100 concurrent stores per wave; arrays are then sized for
                              nblk*blk chains and one-row arrays (innovations, rho, pinv_rank) are [T][nblk*blk].
                              Inputs are never blocked.  epi_ekf_run_host accepts the classic layout only. */
+    int32_t shape;        /* how the 6-state generic models are mapped to lanes (epi_shape): 0 = decide by batch size,
+                             1 = one lane per chain (ekf_fwd_sym / eks_bwd_sym: least total work, what a batch that fills
+                             the chip wants), 2 = four lanes per chain (ekf_fwd_quad / eks_bwd_quad: every 6 x 6 matrix as
+                             a 2 x 2 grid of 3 x 3 blocks over a DPP quad; a ~2x shorter per-day instruction stream and
+                             4x the wavefronts, what a batch that does NOT fill the chip wants -- DESIGN.md 4).  Results
+                             are bit-identical either way.  Ignored by the other models. */
+    int32_t storage;      /* element type of the OUTPUT arrays: 0 = fp64 (the reference's), 1 = fp32 storage with fp64
+                             register arithmetic (BASELINE config 5): every selected output is the fp64 result rounded
+                             once to fp32; the forward quantities the smoother reads back stay fp64 in the workspace.
+                             epi_ekf_run_device only. */
 } epi_batch_desc;
+
+typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2 } epi_shape;
 
 typedef struct epi_inputs {
     const int32_t *x_series; /* [B] or NULL */

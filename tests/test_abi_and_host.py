@@ -195,7 +195,7 @@ def test_rt_expfit_validate_and_tools_errors(hip_lib):
 
     def d(**kw):
         r = _lib.RtDesc()
-        base = dict(abi_version=1, B=4, T=10, Sx=4, L=21, order=1); base.update(kw)
+        base = dict(abi_version=_lib.ABI_VERSION, B=4, T=10, Sx=4, L=21, order=1); base.update(kw)
         for k, v in base.items():
             setattr(r, k, v)
         return r
@@ -249,7 +249,7 @@ def test_simulator_entry_points_reject_bad_arguments_without_a_gpu(hip_lib):
     assert hip_lib.epi_si_controlled_host(0, 5, 1, 0.1, None, p, p, p, p, 0, err) == -5
     assert hip_lib.epi_seirp_sim_host(1, 0, 1, 0.1, 0, 0, p, p, None, p, 0, err) == -5
     d = _lib.SimDesc()
-    d.abi_version, d.B, d.K, d.Su, d.n_npi = 1, 1, 0, 1, 3
+    d.abi_version, d.B, d.K, d.Su, d.n_npi = _lib.ABI_VERSION, 1, 0, 1, 3
     assert hip_lib.epi_sialpha_sim_host(C.byref(d), None, p, p, None, p, p, p, None, None, 0, err) == -5
     d.K, d.u_block = 4, 8
     assert hip_lib.epi_sialpha_sim_host(C.byref(d), None, p, p, None, p, p, p, None, None, 0, err) == -5
