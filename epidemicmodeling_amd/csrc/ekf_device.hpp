@@ -254,6 +254,9 @@ EPI_DEV void resolve_control(const PRM &p, const ModelFlags &mf, const double (&
     }
 }
 
+template <int M, int FLIP, class PRM>
+EPI_DEV void state_map(const PRM &p, double dot, const double (&s)[M], double (&sn)[M]);
+
 // NlinStateUpdate: SIAlphaModelEKF.m:39-48, OptControlled.m:39-74, Backward*.m:60-95.
 // `u` comes in with NaNs and leaves as the control actually applied (u_opt).
 template <int M, int FLIP, class PRM>
@@ -265,6 +268,13 @@ EPI_DEV void nlin_state_update(const PRM &p, const ModelFlags &mf, double (&u)[k
     double dot = (p.gamma * p.A(0)) * (p.Umax(0) - u[0]);
 #pragma unroll
     for (int k = 1; k < kNpi; k++) dot = fma(p.gamma * p.A(k), p.Umax(k) - u[k], dot);
+    state_map<M, FLIP>(p, dot, s, sn);
+}
+
+// the Euler maps themselves, given dot = (gamma*a') * (u_max - u)   (shared by the one-lane and the four-lane kernels)
+template <int M, int FLIP, class PRM>
+EPI_DEV void state_map(const PRM &p, double dot, const double (&s)[M], double (&sn)[M])
+{
     const double asi = s[2] * s[0] * s[1];
     const double f3 = -p.gamma * s[2] + p.gamma * p.b + dot;
     if (!FLIP) {
@@ -312,8 +322,38 @@ EPI_DEV void obs_jacobian(const ModelFlags &mf, const double (&s)[M], double (&C
 
 // StateJacobians: SIAlphaModelEKF.m:62-76, OptControlled.m:89-135, Backward*.m:83-97 / :109-156.
 // `u` is the ORIGINAL control column (NaNs kept), GenericEKF.m:157,206.
+// linear-slope term A(3,6) of the bang-bang control, OptControlled.m:107-114 (`u` with its NaNs)
+template <int M, int FLIP, class PRM>
+EPI_DEV double slope_term(const PRM &p, const double (&u)[kNpi], const double (&s)[M])
+{
+    double a36 = 0.0;
+    if (M == 6) {
+        const double dt = p.dt;
+        const double gs6 = p.gamma * s[M == 6 ? 5 : 0];
+        const double inv_sigma = 1.0 / p.sigma;
+#pragma unroll
+        for (int k = 0; k < kNpi; k++) {
+            if (is_nan(u[k])) {
+                double phi = p.epsilon * p.W(k) - gs6 * p.A(k);
+                if (phi > -inv_sigma && phi < inv_sigma) {
+                    double term = p.gamma * dt * (p.sigma / 2.0) * p.A(k) * (p.Umax(k) - p.Umin(k));
+                    a36 = FLIP ? (a36 + term) : (a36 - term);
+                }
+            }
+        }
+    }
+    return a36;
+}
+template <int M, int FLIP, class PRM>
+EPI_DEV void jacobian_entries(const PRM &p, const double (&s)[M], double a36, double (&A)[M * M]);
 template <int M, int FLIP, class PRM>
 EPI_DEV void state_jacobians(const PRM &p, const double (&u)[kNpi], const double (&s)[M], double (&A)[M * M])
+{
+    jacobian_entries<M, FLIP>(p, s, slope_term<M, FLIP>(p, u, s), A);
+}
+// the entries of the Jacobian given the slope term (shared by the one-lane and the four-lane kernels)
+template <int M, int FLIP, class PRM>
+EPI_DEV void jacobian_entries(const PRM &p, const double (&s)[M], double a36, double (&A)[M * M])
 {
     const double dt = p.dt;
 #pragma unroll
@@ -337,20 +377,6 @@ EPI_DEV void state_jacobians(const PRM &p, const double (&u)[kNpi], const double
     }
     if (M == 6) {
         constexpr int i3 = (M == 6) ? 3 : 0, i4 = (M == 6) ? 4 : 0, i5 = (M == 6) ? 5 : 0;
-        // linear-slope term of the bang-bang control, OptControlled.m:107-114
-        const double gs6 = p.gamma * s[i5];
-        const double inv_sigma = 1.0 / p.sigma;
-        double a36 = 0.0;
-#pragma unroll
-        for (int k = 0; k < kNpi; k++) {
-            if (is_nan(u[k])) {
-                double phi = p.epsilon * p.W(k) - gs6 * p.A(k);
-                if (phi > -inv_sigma && phi < inv_sigma) {
-                    double term = p.gamma * dt * (p.sigma / 2.0) * p.A(k) * (p.Umax(k) - p.Umin(k));
-                    a36 = FLIP ? (a36 + term) : (a36 - term);
-                }
-            }
-        }
         A[IXM(2, i5)] = a36;
         const double rho = s[i3] - s[i4] - (1.0 - p.epsilon);
         if (!FLIP) {

@@ -20,6 +20,9 @@
 #pragma once
 
 constexpr int kQC = kWave / 4;   // chains per wavefront
+#ifndef EPI_QUAD_WAVES
+#define EPI_QUAD_WAVES 1          // minimum waves per SIMD the quad kernels are compiled for (register cap 512 / n)
+#endif
 
 #define EPI_QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
 constexpr int QP_ROW_L = EPI_QP(0, 0, 2, 2);   // block (bi, 0) of my block row
@@ -69,69 +72,127 @@ EPI_DEV void qsym(const blk3 &F, blk3 &P)      // (F + F')/2.0   GenericEKF.m:13
 struct Quad {
     int q, lc;          // lane in the quad, chain in the wavefront
     bool bi, bj;        // block row / block column owned
-    unsigned cpart;     // byte offset of this chain inside a time slice of a 36-row array, + my block's first row
 };
 
 // --- addressing of the chain-blocked arrays (see Lay): element (row e, chain c) of slice t -------------------------
-// vector arrays (6 rows): quad lane q holds rows q and q + 4
+// BLK > 0: the layout's lane_block is that compile-time constant (16 = one block per quad wavefront, what the host
+// chooses for this shape): the row pitch is BLK * 8 bytes, every row offset folds into the instruction's 12-bit immediate
+// and no SGPR holds one.  BLK = 0: any layout, row offsets in SGPRs (as in ekf_sym.hpp).
+template <int BLK>
+EPI_DEV rsrc_t qslice(const double *p, int t, unsigned rows, const Lay &l, unsigned &voff, unsigned &rowb)
+{
+    if (BLK) {
+        rowb = (unsigned)BLK * 8u;
+        voff = (l.cb * rows * (unsigned)BLK + l.cr) * 8u;
+        return mk_rsrc(p + (size_t)t * rows * l.bp, rows * l.bp * 8u);
+    }
+    return lay_slice(p, t, rows, l, voff, rowb);
+}
+template <int BLK> EPI_DEV double qld(rsrc_t r, unsigned vo, unsigned row, unsigned rowb)
+{
+    return BLK ? bld(r, vo + row * ((unsigned)BLK * 8u), 0u) : bld(r, vo, row * rowb);
+}
+template <int BLK> EPI_DEV void qst(rsrc_t r, unsigned vo, unsigned row, unsigned rowb, double v)
+{
+    if (BLK) bst(r, vo + row * ((unsigned)BLK * 8u), 0u, v); else bst(r, vo, row * rowb, v);
+}
+// vector arrays (6 rows): quad lane q stores rows q and 4 + (q & 1) -- lanes 2, 3 repeat what lanes 0, 1 store in the
+// second instruction (same value, same address), so no lane is ever masked off
+template <int BLK>
 EPI_DEV void qstore_vec(double *__restrict__ dst, int t, const Lay &l, const Quad &Q, const double (&v)[6])
 {
     if (!dst) return;
     unsigned voff, rowb;
-    const rsrc_t r = lay_slice(dst, t, 6, l, voff, rowb);
+    const rsrc_t r = qslice<BLK>(dst, t, 6, l, voff, rowb);
     const double lo = (Q.q == 0) ? v[0] : (Q.q == 1) ? v[1] : (Q.q == 2) ? v[2] : v[3];
     const double hi = (Q.q & 1) ? v[5] : v[4];
-    bst(r, voff + (unsigned)Q.q * rowb, 0u, lo);
-    if (Q.q < 2) bst(r, voff + (unsigned)Q.q * rowb, 4u * rowb, hi);
+    qst<BLK>(r, voff + (unsigned)Q.q * rowb, 0u, rowb, lo);
+    qst<BLK>(r, voff + (unsigned)(Q.q & 1) * rowb, 4u, rowb, hi);
 }
+template <int BLK>
 EPI_DEV void qload_vec(const double *__restrict__ src, int t, const Lay &l, double (&v)[6])
 {
     unsigned voff, rowb;
-    const rsrc_t r = lay_slice(src, t, 6, l, voff, rowb);
+    const rsrc_t r = qslice<BLK>(src, t, 6, l, voff, rowb);
 #pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = bld(r, voff, (unsigned)i * rowb);
+    for (int i = 0; i < 6; i++) v[i] = qld<BLK>(r, voff, (unsigned)i, rowb);
 }
-// my 3 x 3 block of a 6 x 6 array stored with all 36 rows (row e = i + 6 j).  upper_only: entries below the diagonal
-// are not written (workspace that is only read back through qload_sym_blk / eks_pinv)
-EPI_DEV void qstore_blk(double *__restrict__ dst, int t, const Lay &l, const Quad &Q, const blk3 &Bk, bool upper_only)
+// one-row arrays ([T][nblk*blk]: innovations, rho, rank words): the four lanes of a quad store the same word
+template <class TV>
+EPI_DEV void qstore_scalar(TV *__restrict__ dst, int t, const Lay &l, TV v)
+{
+    if (dst) dst[lay_scalar(t, l)] = v;
+}
+// my 3 x 3 block of a 6 x 6 array stored with all 36 rows (row e = i + 6 j).  Always the full matrix, also where the
+// one-lane kernels store the upper triangle only (workspace): this shape runs batches that do not fill the chip, where
+// an unmasked store costs less than the exec-mask bookkeeping around a masked one
+template <int BLK>
+EPI_DEV void qstore_blk(double *__restrict__ dst, int t, const Lay &l, const Quad &Q, const blk3 &Bk)
 {
     if (!dst) return;
     unsigned voff, rowb;
-    const rsrc_t r = lay_slice(dst, t, 36, l, voff, rowb);
+    const rsrc_t r = qslice<BLK>(dst, t, 36, l, voff, rowb);
     const unsigned vo = voff + (unsigned)((Q.bi ? 3 : 0) + (Q.bj ? 18 : 0)) * rowb;
-    const bool le = !(Q.bi && !Q.bj), lt = (!Q.bi && Q.bj);     // block row <= / < block column
 #pragma unroll
     for (int c = 0; c < 3; c++)
 #pragma unroll
-        for (int rr = 0; rr < 3; rr++) {
-            const bool ok = !upper_only || (rr <= c ? le : lt);
-            if (ok) bst(r, vo, (unsigned)(rr + 6 * c) * rowb, Bk[rr][c]);
-        }
+        for (int rr = 0; rr < 3; rr++) qst<BLK>(r, vo, (unsigned)(rr + 6 * c), rowb, Bk[rr][c]);
 }
 // my block of a SYMMETRIC 6 x 6 array of which only the upper triangle may be stored: element (i, j) is read from
 // row min + 6 max.  rows36 = false: the packed 21-row form (row i + j (j + 1) / 2, i <= j) of eks_pinv's X.
+// The nine per-lane byte offsets (chain part included) are formed once per kernel.
 struct QOff { unsigned o[3][3]; };
-EPI_DEV QOff qoffsets(const Quad &Q, unsigned rowb, bool rows36)
+template <int BLK>
+EPI_DEV QOff qoffsets(const Quad &Q, const Lay &l, bool rows36)
 {
     QOff f;
+    const unsigned rows = rows36 ? 36u : 21u, blk = BLK ? (unsigned)BLK : l.blk;
+    const unsigned base = (l.cb * rows * blk + l.cr) * 8u, rowb = blk * 8u;
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + c;
             const int lo = i < j ? i : j, hi = i < j ? j : i;
-            f.o[r][c] = (unsigned)(rows36 ? lo + 6 * hi : lo + hi * (hi + 1) / 2) * rowb;
+            f.o[r][c] = base + (unsigned)(rows36 ? lo + 6 * hi : lo + hi * (hi + 1) / 2) * rowb;
         }
     return f;
 }
 EPI_DEV void qload_sym_blk(const double *__restrict__ src, int t, const Lay &l, const QOff &f, unsigned rows, blk3 &Bk)
 {
-    unsigned voff, rowb;
-    const rsrc_t r = lay_slice(src, t, rows, l, voff, rowb);
+    const rsrc_t r = mk_rsrc(src + (size_t)t * rows * l.bp, rows * l.bp * 8u);
 #pragma unroll
     for (int rr = 0; rr < 3; rr++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) Bk[rr][c] = bld(r, voff + f.o[rr][c], 0u);
+        for (int c = 0; c < 3; c++) Bk[rr][c] = bld(r, f.o[rr][c], 0u);
+}
+
+// --- the innovation monitor's windows (GenericEKF.m:172-179) --------------------------------------------------------
+// A window of L samples is a ring in LDS written TWICE (at pos and pos + L of a 2L-long column): the L samples newest ->
+// oldest are then the contiguous run pos .. pos + L - 1, read with immediate offsets and no wrap arithmetic.
+// LC > 0: L is that compile-time constant (21 is what every caller of the reference passes) and the sum is fully unrolled.
+template <int LC>
+EPI_DEV double qring_sum(const double *newest_ptr, int L, double newest)
+{
+    double sum = newest;
+    if (LC) {
+        double v[LC > 1 ? LC - 1 : 1];
+#pragma unroll
+        for (int j = 1; j < LC; j++) v[j - 1] = newest_ptr[j * kQC];
+#pragma unroll
+        for (int j = 1; j < LC; j++) sum = sum + v[j - 1];
+        return sum;
+    }
+    int j = 1;
+    for (; j + 10 <= L; j += 10) {
+        double v[10];
+#pragma unroll
+        for (int q = 0; q < 10; q++) v[q] = newest_ptr[(j + q) * kQC];
+#pragma unroll
+        for (int q = 0; q < 10; q++) sum = sum + v[q];
+    }
+    for (; j < L; j++) sum = sum + newest_ptr[j * kQC];
+    return sum;
 }
 
 // rows of the Jacobian a lane multiplies with: its block row's (bi) and its block column's (bj)
@@ -195,7 +256,8 @@ EPI_DEV void qmul(const blk3 &Ll, const blk3 &Lr, const blk3 &Rt, const blk3 &Rb
 }
 
 // P(k+1|k) = sym(A P(k|k) A' + Q), Q diagonal (GenericEKF.m:158-161): blocks in, blocks out (cf. predict_cov_sym)
-EPI_DEV void qpredict_cov(const Quad &Q, const double (&A)[36], const blk3 &Pp, const double (&Qd)[6], blk3 &Pm)
+// Qadd[r]: Q_w(i, i) of my block's diagonal entries for the lanes (0,0), (1,1), 0.0 for the off-diagonal blocks
+EPI_DEV void qpredict_cov(const Quad &Q, const double (&A)[36], const blk3 &Pp, const double (&Qadd)[3], blk3 &Pm)
 {
     double Ar[3][6], Ac[3][6];
     qrows(A, Q.bi, Ar);
@@ -207,47 +269,152 @@ EPI_DEV void qpredict_cov(const Quad &Q, const double (&A)[36], const blk3 &Pp, 
     qx3<QP_ROW_L>(T1, T1l);
     qx3<QP_ROW_R>(T1, T1r);
     qmul_bt(T1l, T1r, Ac, G);                  // G = T1 A'
-    const bool dg = (Q.bi == Q.bj);
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const double qv = (r == c && dg) ? (Q.bi ? Qd[3 + r] : Qd[r]) : 0.0;
-            G[r][c] = G[r][c] + qv;
-        }
+        for (int c = 0; c < 3; c++) G[r][c] = G[r][c] + ((r == c) ? Qadd[r] : 0.0);
     qsym(G, Pm);
+}
+
+// --- the model's NPI vectors, three NPIs per lane ------------------------------------------------------------------
+// Lane q of a quad owns NPIs k = q, q + 4, q + 8: it loads u(k), resolves a free control (NaN) and forms u_max(k) - u(k)
+// and the slope-term contribution for them; the two sequential reductions over k (the fma chain of (gamma a')(u_max - u)
+// and the running a36 -= term) are then run by every lane on operands fetched from their owners by DPP broadcast.
+struct QPrm { double dt, beta, gamma, sigma, b, epsilon, slo, ilo, alpha_min, alpha_max; };
+struct QNpi {
+    double a[3], umin[3], umax[3], ew[3], term[3];   // a(k), u_min(k), u_max(k), epsilon*w(k), gamma*dt*(sigma/2)*a(k)*(u_max(k)-u_min(k))
+    double inv_sigma;
+    const double *ga;                                // LDS column of this chain: gamma * a(k), k = 0..11, stride kQC
+};
+EPI_DEV void qload_prm(QPrm &p, QNpi &n, const KArgs &a, int B, int c, const Quad &Q, double *ga_col)
+{
+    auto g = [&](int f) { return a.prm[(size_t)f * B + c]; };
+    p.dt = g(EPI_PRM_DT); p.beta = g(EPI_PRM_BETA); p.gamma = g(EPI_PRM_GAMMA);
+    p.sigma = g(EPI_PRM_SIGMA); p.b = g(EPI_PRM_B); p.epsilon = g(EPI_PRM_EPSILON);
+    p.slo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_S_MIN);
+    p.ilo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_I_MIN);
+    p.alpha_min = g(EPI_PRM_ALPHA_MIN); p.alpha_max = g(EPI_PRM_ALPHA_MAX);
+    n.inv_sigma = 1.0 / p.sigma;
+    n.ga = ga_col;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int k = Q.q + 4 * s;
+        n.a[s] = g(EPI_PRM_A + k); n.umin[s] = g(EPI_PRM_U_MIN + k); n.umax[s] = g(EPI_PRM_U_MAX + k);
+        n.ew[s] = p.epsilon * g(EPI_PRM_W_EFF + k);
+        // same products, same order as slope_term() / nlin_state_update(): constants of the chain, formed once
+        n.term[s] = p.gamma * p.dt * (p.sigma / 2.0) * n.a[s] * (n.umax[s] - n.umin[s]);
+        ga_col[k * kQC] = p.gamma * n.a[s];
+    }
+}
+// u(k, t) for my three NPIs (rows beyond n_npi read 0.0 through the descriptor's bounds check, see load_u)
+EPI_DEV void qload_u(const KArgs &a, int t, int su, const Quad &Q, double (&u3)[3])
+{
+    const unsigned rowb = (unsigned)a.Su * 8u, voff = (unsigned)su * 8u + (unsigned)Q.q * rowb;
+    const rsrc_t r = mk_rsrc(a.u + (size_t)t * a.n_npi * a.Su, (unsigned)a.n_npi * rowb);
+#pragma unroll
+    for (int s = 0; s < 3; s++) u3[s] = bld(r, voff, (unsigned)(4 * s) * rowb);
+}
+template <int BLK>
+EPI_DEV void qstore_u(double *__restrict__ dst, const KArgs &a, int t, const Lay &l, const Quad &Q, const double (&u3)[3])
+{
+    if (!dst) return;
+    unsigned voff, rowb;
+    const rsrc_t r = qslice<BLK>(dst, t, (unsigned)a.n_npi, l, voff, rowb);
+    const unsigned vo = voff + (unsigned)Q.q * rowb;
+    if (a.n_npi == kNpi) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) qst<BLK>(r, vo, (unsigned)(4 * s), rowb, u3[s]);
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+        if (Q.q + 4 * s < a.n_npi) qst<BLK>(r, vo, (unsigned)(4 * s), rowb, u3[s]);
+}
+// bang-bang substitution of my NaN controls, OptControlled.m:49-58 (resolve_control); phi(k) is kept for the slope term
+EPI_DEV void qresolve(const QPrm &p, const QNpi &n, const ModelFlags &mf, double s6, const double (&u3)[3], double (&ur)[3],
+                      double (&phi)[3])
+{
+    const double gs6 = p.gamma * s6;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        phi[s] = n.ew[s] - gs6 * n.a[s];
+        const bool lo = mf.phi_ge ? (phi[s] >= 0.0) : (phi[s] > 0.0);
+        ur[s] = is_nan(u3[s]) ? (lo ? n.umin[s] : n.umax[s]) : u3[s];
+    }
+}
+template <int J> EPI_DEV double qbc(double v) { return qx<EPI_QP(J, J, J, J)>(v); }
+// all twelve values of a three-per-lane vector, in NPI order k = 4 s + owner lane
+EPI_DEV void qgather12(const double (&v3)[3], double (&v)[kNpi])
+{
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        v[4 * s + 0] = qbc<0>(v3[s]); v[4 * s + 1] = qbc<1>(v3[s]);
+        v[4 * s + 2] = qbc<2>(v3[s]); v[4 * s + 3] = qbc<3>(v3[s]);
+    }
+}
+// (gamma a') (u_max - u): the k-ascending fma chain of nlin_state_update()
+EPI_DEV double qdot(const QNpi &n, const double (&ur)[3])
+{
+    double d3[3], d[kNpi];
+#pragma unroll
+    for (int s = 0; s < 3; s++) d3[s] = n.umax[s] - ur[s];
+    qgather12(d3, d);
+    double dot = n.ga[0] * d[0];
+#pragma unroll
+    for (int k = 1; k < kNpi; k++) dot = fma(n.ga[k * kQC], d[k], dot);
+    return dot;
+}
+// slope_term(): a36 -= term(k) (+= for the time-flipped models) for every free control with |phi(k)| < 1/sigma, k ascending.
+// A control that does not qualify contributes -(+0.0): a36 never is -0.0, so that leaves it bit-wise unchanged.
+template <int FLIP>
+EPI_DEV double qslope(const QNpi &n, const double (&u3)[3], const double (&phi)[3])
+{
+    const bool any_free = is_nan(u3[0]) || is_nan(u3[1]) || is_nan(u3[2]);
+    if (__builtin_amdgcn_ballot_w64(any_free) == 0ull) return 0.0;      // historic days: no lane of the wave has one
+    double tm3[3], tm[kNpi];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+        tm3[s] = (is_nan(u3[s]) && phi[s] > -n.inv_sigma && phi[s] < n.inv_sigma) ? n.term[s] : 0.0;
+    qgather12(tm3, tm);
+    double a36 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) a36 = FLIP ? (a36 + tm[k]) : (a36 - tm[k]);
+    return a36;
 }
 
 // ---------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------
-template <int FLIP>
-__global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *__restrict__ dense_flag)
+template <int FLIP, int BLK, int LC>
+__global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void ekf_fwd_quad(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
-    extern __shared__ double lds[];   // windows [3][L][kQC] + model vectors [48][kQC], one column per chain
+    extern __shared__ double lds[];   // windows [3][2 L][kQC] + gamma*a [12][kQC], one column per chain
     if (*dense_flag) return;
     Quad Q;
     Q.q = threadIdx.x & 3; Q.lc = threadIdx.x >> 2; Q.bi = (Q.q >> 1) != 0; Q.bj = (Q.q & 1) != 0;
     const int c = a.c0 + blockIdx.x * kQC + Q.lc;
     if (c >= a.c0 + a.cn) return;               // whole quads leave together
-    const int B = a.B, T = a.T, L = a.L;
+    const int B = a.B, T = a.T, L = LC ? LC : a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
-    constexpr int stride = kQC;
-    LitePrm<VecLdsS> p;
-    init_prm<M>(p, a, B, c, lds + (size_t)3 * L * stride + Q.lc, stride);   // (the four lanes write the same values)
+    QPrm p;
+    QNpi np;
+    qload_prm(p, np, a, B, c, Q, lds + (size_t)6 * L * kQC + Q.lc);
     const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
     const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
     const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
 
-    double sk_minus[M], Qd[M];
+    double sk_minus[M], Qadd[3];
     blk3 Pm;
 #pragma unroll
-    for (int i = 0; i < M; i++) {
-        sk_minus[i] = a.s_init[(size_t)i * B + c];
-        Qd[i] = a.Q[(size_t)IXM(i, i) * B + c];
+    for (int i = 0; i < M; i++) sk_minus[i] = a.s_init[(size_t)i * B + c];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int i = (Q.bi ? 3 : 0) + r;
+        const double qd = a.Q[(size_t)IXM(i, i) * B + c];
+        Qadd[r] = (Q.bi == Q.bj) ? qd : 0.0;
     }
     // Ps_init is bit-wise symmetric (ekf_precheck); the packed kernel reads its upper triangle, so do we
 #pragma unroll
@@ -258,9 +425,10 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
             Pm[r][cc] = a.Ps_init[(size_t)(i < j ? IXM(i, j) : IXM(j, i)) * B + c];
         }
 
-    double *winMean = lds + Q.lc, *winCov = lds + (size_t)L * stride + Q.lc, *winCovN = lds + (size_t)2 * L * stride + Q.lc;
-    for (int j = 0; j < L; j++) { winMean[j * stride] = 0.0; winCov[j * stride] = 0.0; winCovN[j * stride] = 0.0; }
-    int head = 0;
+    // three windows, each a 2L-long column per chain (see qring_sum); `pos` = where the newest sample sits
+    double *winMean = lds + Q.lc, *winCov = lds + (size_t)2 * L * kQC + Q.lc, *winCovN = lds + (size_t)4 * L * kQC + Q.lc;
+    for (int j = 0; j < 2 * L; j++) { winMean[j * kQC] = 0.0; winCov[j * kQC] = 0.0; winCovN[j * kQC] = 0.0; }
+    int pos = 0;
     const bool fixed_R = (a.r_mode == 0);
     const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
     double R_next = R_v;
@@ -268,25 +436,25 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
     const unsigned voff_x = (unsigned)sx * 8u;
     double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(0, T) * a.Sx, voff_x);
     double r_nxt = fixed_R ? 0.0 : ldg(a.R_series, voff_x);
-    double u_nxt[kNpi];
-    load_u(a, tpos<FLIP>(0, T), su, u_nxt);
+    double u_nxt[3];
+    qload_u(a, tpos<FLIP>(0, T), su, Q, u_nxt);
 
     for (int k = 0; k < T; k++) {
         const int t = tpos<FLIP>(k, T);
         const double Rk = fixed_R ? R_next : r_nxt;
         const double xk = x_nxt;
-        double u_in[kNpi];
+        double u_in[3];
 #pragma unroll
-        for (int qq = 0; qq < kNpi; qq++) u_in[qq] = u_nxt[qq];
+        for (int qq = 0; qq < 3; qq++) u_in[qq] = u_nxt[qq];
         if (k + 1 < T) {
             const int tn = tpos<FLIP>(k + 1, T);
             x_nxt = ldg(a.x + (size_t)tn * a.Sx, voff_x);
             if (!fixed_R) r_nxt = ldg(a.R_series + (size_t)(k + 1) * a.Sx, voff_x);
-            load_u(a, tn, su, u_nxt);
+            qload_u(a, tn, su, Q, u_nxt);
         }
 
-        qstore_vec(a.S_MINUS, t, lay, Q, sk_minus);
-        qstore_blk(a.P_MINUS, t, lay, Q, Pm, (a.ws_upper & 1) != 0);
+        qstore_vec<BLK>(a.S_MINUS, t, lay, Q, sk_minus);
+        qstore_blk<BLK>(a.P_MINUS, t, lay, Q, Pm);
 
         double C[M];
         obs_jacobian<M>(a.mf, sk_minus, C);                 // C(4:6) == 0
@@ -308,7 +476,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
             }
             double PC0[3];
 #pragma unroll
-            for (int r = 0; r < 3; r++) PC0[r] = qx<EPI_QP(0, 0, 0, 0)>(PCr[r]);
+            for (int r = 0; r < 3; r++) PC0[r] = qbc<0>(PCr[r]);
             double CPCt = PC0[0] * C[0];
             CPCt = fma(PC0[1], C[1], CPCt);
             CPCt = fma(PC0[2], C[2], CPCt);
@@ -318,8 +486,8 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
             for (int r = 0; r < 3; r++) Kr[r] = PCr[r] / den;
 #pragma unroll
             for (int r = 0; r < 3; r++) {
-                K[r] = qx<EPI_QP(0, 0, 0, 0)>(Kr[r]);
-                K[3 + r] = qx<EPI_QP(2, 2, 2, 2)>(Kr[r]);
+                K[r] = qbc<0>(Kr[r]);
+                K[3 + r] = qbc<2>(Kr[r]);
                 Kc[r] = Q.bj ? K[3 + r] : K[r];
             }
             // (I - K C): my block row's and my block column's rows of its first three columns
@@ -368,40 +536,45 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
 #pragma unroll
                 for (int cc = 0; cc < 3; cc++) Pp[r][cc] = Pm[r][cc];
         }
+        qstore_vec<BLK>(a.K_GAIN, t, lay, Q, K);
+        qstore_scalar(a.innovations, t, lay, innov);
         state_hard_margins<M>(p, sk_plus);
+        qstore_vec<BLK>(a.S_PLUS, t, lay, Q, sk_plus);
+        qstore_blk<BLK>(a.P_PLUS, t, lay, Q, Pp);
 
-        double u_app[kNpi];
-#pragma unroll
-        for (int qq = 0; qq < kNpi; qq++) u_app[qq] = u_in[qq];
-        nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
-        if (Q.q == 0) store_u(a.u_opt, a, t, lay, u_app);
+        // s(k+1|k) = NlinStateUpdate(u, s+), A = StateJacobians(u, s+)  :155-157 (phi(k) serves both)
+        double u_app[3], phi[3];
+        qresolve(p, np, a.mf, sk_plus[5], u_in, u_app, phi);
+        state_map<M, FLIP>(p, qdot(np, u_app), sk_plus, sk_minus);
+        qstore_u<BLK>(a.u_opt, a, t, lay, Q, u_app);
         {
             double A[M * M];
-            state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
-            qpredict_cov(Q, A, Pp, Qd, Pm);
+            jacobian_entries<M, FLIP>(p, sk_plus, qslope<FLIP>(np, u_in, phi), A);
+            qpredict_cov(Q, A, Pp, Qadd, Pm);
         }
         state_hard_margins<M>(p, sk_minus);
 
-        qstore_vec(a.S_PLUS, t, lay, Q, sk_plus);
-        qstore_blk(a.P_PLUS, t, lay, Q, Pp, (a.ws_upper & 2) != 0);
-        qstore_vec(a.K_GAIN, t, lay, Q, K);
-        if (a.innovations && Q.q == 0) a.innovations[lay_scalar(t, lay)] = innov;
-
-        // innovation monitor (identical to ekf_fwd_sym; the four lanes of a quad compute the same numbers)
+        // innovation monitor :172-179 (identical arithmetic to ekf_fwd_sym; the four lanes of a quad hold the same numbers)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
-        head = (head == 0) ? (L - 1) : (head - 1);
-        winMean[head * stride] = innov;
-        const double sum = ring_sum(winMean, head, L, innov, stride);
+        pos = (pos == 0) ? (L - 1) : (pos - 1);
+        double *wm = winMean + pos * kQC;
+        wm[0] = innov; wm[L * kQC] = innov;
+        const double sum = qring_sum<LC>(wm, L, innov);
         const double mu = sum / (double)cnt;
         const double cc2 = (innov - mu) * (innov - mu);
         const double ccn = cc2 / (Rk + kEps);
-        winCov[head * stride] = cc2;
-        winCovN[head * stride] = ccn;
-        const double sumN = ring_sum(winCovN, head, L, ccn, stride);
-        if (a.rho && Q.q == 0) a.rho[lay_scalar(k, lay)] = sumN / (double)cnt;   // filter-step order (see ekf_fwd_sym)
+        double *wc = winCov + pos * kQC, *wn = winCovN + pos * kQC;
+        wc[0] = cc2; wc[L * kQC] = cc2;
+        wn[0] = ccn; wn[L * kQC] = ccn;
+        // the two remaining window sums are independent: even lanes of the quad add up the normalised window, odd
+        // lanes the plain one (needed for the adaptive R only), each strictly newest -> oldest
+        const bool odd = fixed_R && (Q.q & 1);
+        const double s2 = qring_sum<LC>(odd ? wc : wn, L, odd ? cc2 : ccn);
+        const double sumN = qbc<0>(s2);
+        qstore_scalar(a.rho, k, lay, sumN / (double)cnt);     // filter-step order also when FLIP (see ekf_fwd_sym)
         if (fixed_R) {
+            const double sumC = qbc<1>(s2);
             if (beta != 1.0 && valid && k < T - 1) {
-                const double sumC = ring_sum(winCov, head, L, cc2, stride);
                 R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);
             } else {
                 R_next = R_v;
@@ -413,11 +586,11 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
 // ---------------------------------------------------------------------------
 // backward recursion (X = pinv(P_MINUS) comes from eks_pinv, packed)
 // ---------------------------------------------------------------------------
-template <int FLIP>
-__global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *__restrict__ dense_flag)
+template <int FLIP, int BLK>
+__global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void eks_bwd_quad(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
-    __shared__ double vlds[4 * kNpi * kQC];
+    __shared__ double galds[kNpi * kQC];   // gamma * a(k), one column per chain
     if (*dense_flag) return;
     Quad Q;
     Q.q = threadIdx.x & 3; Q.lc = threadIdx.x >> 2; Q.bi = (Q.q >> 1) != 0; Q.bj = (Q.q & 1) != 0;
@@ -426,16 +599,16 @@ __global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
-    LitePrm<VecLdsS> p;
-    init_prm<M>(p, a, B, c, vlds + Q.lc, kQC);
-    const unsigned rowb = lay.blk * 8u;
-    const QOff o36 = qoffsets(Q, rowb, true), o21 = qoffsets(Q, rowb, false);
+    QPrm p;
+    QNpi np;
+    qload_prm(p, np, a, B, c, Q, galds + Q.lc);
+    const QOff o36 = qoffsets<BLK>(Q, lay, true), o21 = qoffsets<BLK>(Q, lay, false);
 
     // terminal conditions GenericEKF.m:189-202 (Ps_final symmetric in values and NaN pattern: ekf_precheck)
     double Ss[M];
     blk3 Ps;
     const int tT = tpos<FLIP>(T - 1, T);
-    qload_vec(a.S_PLUS, tT, lay, Ss);
+    qload_vec<BLK>(a.S_PLUS, tT, lay, Ss);
 #pragma unroll
     for (int i = 0; i < M; i++) {
         const double f = a.s_final[(size_t)i * B + c];
@@ -450,31 +623,33 @@ __global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *
             const double f = a.Ps_final[(size_t)(i < j ? IXM(i, j) : IXM(j, i)) * B + c];
             if (!is_nan(f)) Ps[r][cc] = f;
         }
-    qstore_vec(a.S_SMOOTH, tT, lay, Q, Ss);
-    qstore_blk(a.P_SMOOTH, tT, lay, Q, Ps, false);
-    if (a.u_opt_smooth && Q.q == 0) {
-        double z[kNpi];
-#pragma unroll
-        for (int k = 0; k < kNpi; k++) z[k] = 0.0;
-        store_u(a.u_opt_smooth, a, tT, lay, z);
+    qstore_vec<BLK>(a.S_SMOOTH, tT, lay, Q, Ss);
+    qstore_blk<BLK>(a.P_SMOOTH, tT, lay, Q, Ps);
+    if (a.u_opt_smooth) {
+        const double z[3] = {0.0, 0.0, 0.0};
+        qstore_u<BLK>(a.u_opt_smooth, a, tT, lay, Q, z);
     }
-    if (a.pinv_rank && Q.q == 0) a.pinv_rank[lay_scalar(tT, lay)] = -1;
+    qstore_scalar(a.pinv_rank, tT, lay, (int32_t)-1);
 
     int st_guard = 0, st_cap = 0, min_rank = M;
     for (int k = T - 2; k >= 0; k--) {
         const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
-        double Sp[M], Sm1[M], u_in[kNpi];
+        double Sp[M], Sm1[M], u_in[3];
         blk3 Pp, X, Pm1;
-        qload_vec(a.S_PLUS, t, lay, Sp);
-        load_u(a, t, su, u_in);
+        qload_vec<BLK>(a.S_PLUS, t, lay, Sp);
+        qload_u(a, t, su, Q, u_in);
         const int rk = a.rankbuf[lay_scalar(t1, lay)];
         qload_sym_blk(a.P_PLUS, t, lay, o36, 36, Pp);
         qload_sym_blk(a.X, t1, lay, o21, 21, X);             // (garbage where the :211 guard fired, rk < 0: unused)
-        qload_vec(a.S_MINUS, t1, lay, Sm1);
+        qload_vec<BLK>(a.S_MINUS, t1, lay, Sm1);
         qload_sym_blk(a.P_MINUS, t1, lay, o36, 36, Pm1);
 
         double A[M * M];
-        state_jacobians<M, FLIP>(p, u_in, Sp, A);              // :206
+        {
+            double ur_unused[3], phi[3];
+            qresolve(p, np, a.mf, Sp[5], u_in, ur_unused, phi);
+            jacobian_entries<M, FLIP>(p, Sp, qslope<FLIP>(np, u_in, phi), A);   // :206
+        }
         blk3 J;
         int rank = -1;
         if (rk < 0) {                                          // non-finite P_MINUS guard :211-213
@@ -558,14 +733,14 @@ __global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *
         }
 #pragma unroll
         for (int i = 0; i < M; i++) Ss[i] = Sn[i];
-        if (a.pinv_rank && Q.q == 0) a.pinv_rank[lay_scalar(t, lay)] = rank;
-        qstore_vec(a.S_SMOOTH, t, lay, Q, Ss);
-        qstore_blk(a.P_SMOOTH, t, lay, Q, Ps, false);
-        if (a.u_opt_smooth) {                                  // :229
-            double sn_unused[M];
-            nlin_state_update<M, FLIP>(p, a.mf, u_in, Ss, sn_unused);
-            if (Q.q == 0) store_u(a.u_opt_smooth, a, t, lay, u_in);
+        qstore_scalar(a.pinv_rank, t, lay, (int32_t)rank);
+        qstore_vec<BLK>(a.S_SMOOTH, t, lay, Q, Ss);
+        qstore_blk<BLK>(a.P_SMOOTH, t, lay, Q, Ps);
+        if (a.u_opt_smooth) {                                  // :229 -- only the control NlinStateUpdate returns is kept
+            double ur[3], phi_unused[3];
+            qresolve(p, np, a.mf, Ss[5], u_in, ur, phi_unused);
+            qstore_u<BLK>(a.u_opt_smooth, a, t, lay, Q, ur);
         }
     }
-    if (a.status && Q.q == 0) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+    if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }

@@ -905,8 +905,12 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
             // four lanes per chain: 16 chains per wavefront (ekf_quad.hpp); the dense fall-back keeps its own mapping
             const int qblocks = (cn + kQC - 1) / kQC;
             if (phase == 0 || phase == 1) {
-                const size_t qshm = ((size_t)3 * ka.L + 4 * kNpi) * kQC * sizeof(double);
-                hipLaunchKernelGGL((ekf_fwd_quad<FLIP>), dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
+                // the specialisation for the layout and the window length this shape is meant for, or the general one
+                const size_t qshm = ((size_t)6 * ka.L + kNpi) * kQC * sizeof(double);
+                if (ka.blk == kQC && ka.L == 21)
+                    hipLaunchKernelGGL((ekf_fwd_quad<FLIP, kQC, 21>), dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
+                else
+                    hipLaunchKernelGGL((ekf_fwd_quad<FLIP, 0, 0>), dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 if (run_dense) {
                     hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
@@ -919,7 +923,8 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             }
             if (phase == 0 || phase == 2 || phase == 4) {
-                hipLaunchKernelGGL((eks_bwd_quad<FLIP>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                if (ka.blk == kQC) hipLaunchKernelGGL((eks_bwd_quad<FLIP, kQC>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((eks_bwd_quad<FLIP, 0>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 if (run_dense) {
                     hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
