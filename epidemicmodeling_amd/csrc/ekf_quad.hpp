@@ -20,6 +20,10 @@
 #pragma once
 
 constexpr int kQC = kWave / 4;   // chains per wavefront
+#ifndef EPI_QUAD_BWD_PF
+#define EPI_QUAD_BWD_PF 0         // smoother: 1 = request a step's inputs one iteration ahead (two register sets); measured
+                                  // level with 0 (1.49 vs 1.46 ms, 9 375 chains): the quad kernels are issue-bound, not latency-bound
+#endif
 #ifndef EPI_QUAD_WAVES
 #define EPI_QUAD_WAVES 1          // minimum waves per SIMD the quad kernels are compiled for (register cap 512 / n)
 #endif
@@ -632,17 +636,27 @@ __global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void eks_bwd_quad(const KArg
     qstore_scalar(a.pinv_rank, tT, lay, (int32_t)-1);
 
     int st_guard = 0, st_cap = 0, min_rank = M;
-    for (int k = T - 2; k >= 0; k--) {
+    // Everything step k reads is requested one iteration ahead (EPI_QUAD_BWD_PF): a lone wave then never sits through a
+    // memory round trip at the top of a step.  Two register sets used alternately (the loop body exists twice), so the
+    // prefetched values are consumed where they landed -- copying them costs more than the latency (measured).
+    struct In { double Sp[M], Sm1[M], u[3]; blk3 Pp, X, Pm1; int rk; };
+    auto fetch = [&](int k, In &d) {
         const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
-        double Sp[M], Sm1[M], u_in[3];
-        blk3 Pp, X, Pm1;
-        qload_vec<BLK>(a.S_PLUS, t, lay, Sp);
-        qload_u(a, t, su, Q, u_in);
-        const int rk = a.rankbuf[lay_scalar(t1, lay)];
-        qload_sym_blk(a.P_PLUS, t, lay, o36, 36, Pp);
-        qload_sym_blk(a.X, t1, lay, o21, 21, X);             // (garbage where the :211 guard fired, rk < 0: unused)
-        qload_vec<BLK>(a.S_MINUS, t1, lay, Sm1);
-        qload_sym_blk(a.P_MINUS, t1, lay, o36, 36, Pm1);
+        qload_vec<BLK>(a.S_PLUS, t, lay, d.Sp);
+        qload_u(a, t, su, Q, d.u);
+        d.rk = a.rankbuf[lay_scalar(t1, lay)];
+        qload_sym_blk(a.P_PLUS, t, lay, o36, 36, d.Pp);
+        qload_sym_blk(a.X, t1, lay, o21, 21, d.X);           // (garbage where the :211 guard fired, rk < 0: unused)
+        qload_vec<BLK>(a.S_MINUS, t1, lay, d.Sm1);
+        qload_sym_blk(a.P_MINUS, t1, lay, o36, 36, d.Pm1);
+    };
+    auto step = [&](int k, In &cur) {
+        const int t = tpos<FLIP>(k, T);
+        const double (&Sp)[M] = cur.Sp;
+        const double (&Sm1)[M] = cur.Sm1;
+        const double (&u_in)[3] = cur.u;
+        const blk3 &Pp = cur.Pp, &X = cur.X, &Pm1 = cur.Pm1;
+        const int rk = cur.rk;
 
         double A[M * M];
         {
@@ -741,6 +755,27 @@ __global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void eks_bwd_quad(const KArg
             qresolve(p, np, a.mf, Ss[5], u_in, ur, phi_unused);
             qstore_u<BLK>(a.u_opt_smooth, a, t, lay, Q, ur);
         }
+    };
+#if EPI_QUAD_BWD_PF
+    {
+        In bufA, bufB;
+        int k = T - 2;
+        if (k >= 0) fetch(k, bufA);
+        while (k >= 0) {
+            if (k > 0) fetch(k - 1, bufB);
+            step(k, bufA);
+            if (--k < 0) break;
+            if (k > 0) fetch(k - 1, bufA);
+            step(k, bufB);
+            --k;
+        }
     }
+#else
+    for (int k = T - 2; k >= 0; k--) {
+        In cur;
+        fetch(k, cur);
+        step(k, cur);
+    }
+#endif
     if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }

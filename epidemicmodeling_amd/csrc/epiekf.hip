@@ -866,10 +866,11 @@ static int balanced_lanes(int cn, int waves_per_simd)
     return (int)(lw > kWave ? kWave : lw);
 }
 
-// Which lane mapping runs the 6-state generic models (epi_batch_desc.shape).  Auto: four lanes per chain while the
-// batch leaves SIMDs without a one-lane-per-chain wave of their own -- then the chains' per-day latency is what
-// counts, and the quad kernels' instruction stream is half as long; one lane per chain (least total work) once every
-// SIMD has one.  Crossover measured on the headline sweep's shards, profiles/r02/batch_size_sweep.txt.
+// Which lane mapping runs the 6-state generic models (epi_batch_desc.shape).  Auto: four lanes per chain while every
+// quad wavefront (16 chains) still gets a SIMD of its own, i.e. up to 16 384 chains on MI355X -- there the chains'
+// per-day latency is what counts and the quad kernels' instruction stream is half as long (9 375 chains: 3.9 instead of
+// 6.1 ms per pass); beyond that the quad waves (one per SIMD at ~290 registers) would run in rounds and one lane per
+// chain, the shape with the least total work, wins (18 750 chains: 7.1 against 9.0 ms).  profiles/r02/batch_size_sweep.txt.
 // EPIEKF_SHAPE=1|2 overrides (measurement).
 static int g_simd_count = 0;
 static int simd_count()
@@ -888,7 +889,7 @@ static bool use_quad(int shape, int m, bool generic, int B)
     if (const char *env = getenv("EPIEKF_SHAPE")) { const int v = atoi(env); if (v == 1 || v == 2) shape = v; }
     if (shape == EPI_SHAPE_QUAD) return true;
     if (shape == EPI_SHAPE_LANE) return false;
-    return (long)B <= (long)simd_count() * kWave / 2;
+    return ((long)B + kQC - 1) / kQC <= (long)simd_count();   // the quad waves still get a SIMD each (one round)
 }
 
 // phase: 0 = everything; 1 = forward kernel; 2 = smoother (pinv + backward); 3 = pinv kernel; 4 = backward kernel

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert set(_lib.ABI_SYMBOLS) == set(names), (names, _lib.ABI_SYMBOLS)
     for n in names:
         assert hasattr(hip_lib, n), f"libepiekf.so does not export {n}"
-    assert hip_lib.epi_abi_version() == 1
+    hdr = int(re.search(r"#define\s+EPIEKF_ABI_VERSION\s+(\d+)", open(os.path.join(H.ROOT, "include", "epiekf.h")).read()).group(1))
+    assert hip_lib.epi_abi_version() == hdr == _lib.ABI_VERSION
 
 
 def test_layout_header_matches_python_mirror():

@@ -67,9 +67,11 @@ def build(draw):
     # process noise: diagonal (packed kernels) or full (dense fallback)
     if generic and draw(st.sampled_from([False, False, True])):
         w.Q = w.Q.copy(); w.Q[1] = 1e-13
-    lane_block = draw(st.sampled_from([0, 0, 3, 8, "auto"]))
+    lane_block = draw(st.sampled_from([0, 0, 3, 8, 16, "auto"]))
     chunks = draw(st.sampled_from([0, 0, 2, -2]))
-    return w, lane_block, chunks, kind
+    # lane mapping of the 6-state generic models: one lane per chain, four lanes per chain, or the library's own choice
+    shape = draw(st.sampled_from(["lane", "quad", "quad", "auto"]))
+    return w, lane_block, chunks, kind, shape
 
 
 # EPI_FUZZ_EXAMPLES=n runs n freshly drawn examples instead of the fixed 200 (a longer hunt; default stays reproducible)
@@ -80,13 +82,13 @@ _N = int(os.environ.get("EPI_FUZZ_EXAMPLES", "0"))
 @given(st.data())
 def test_random_problems_match_the_oracle(gpu_device, data):
     from epidemicmodeling_amd import batch
-    w, lane_block, chunks, kind = build(data.draw)
+    w, lane_block, chunks, kind, shape = build(data.draw)
     ref = H.oracle_batch(w)
-    got = batch.run_workload(w, device=gpu_device, lane_block=lane_block, chunks=chunks)
+    got = batch.run_workload(w, device=gpu_device, lane_block=lane_block, chunks=chunks, shape=shape)
     for n in H.OUT_NAMES:
         if n in ref and n in got:
-            assert np.array_equal(got[n], ref[n], equal_nan=True), (kind, w.T, w.B, w.L, lane_block, chunks, n)
-    assert np.array_equal(got["pinv_rank"], ref["pinv_rank"]), (kind, w.T, w.B)
+            assert np.array_equal(got[n], ref[n], equal_nan=True), (kind, w.T, w.B, w.L, lane_block, chunks, shape, n)
+    assert np.array_equal(got["pinv_rank"], ref["pinv_rank"]), (kind, w.T, w.B, shape)
 
 
 @settings(max_examples=_N or 60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=not _N)
