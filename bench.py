@@ -3,14 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (forward EKF kernel + backward EKS kernel) over one batch of
-synthetic input: BASELINE.json's headline sweep, SIAlphaModelEKFOptControlled over 300 regions x 250
-NPI-cost weights x (400 observed + 120 horizon) days = 75 000 chains x 520 days = 39.0 M region-day
-EKF steps, all 11 reference outputs written (1376 algorithmic bytes per region-day step).  Inputs are
-resident in HBM before the timed region.  With N > 1 every rank (one process per GPU, RCCL) filters its
-own 75 000-chain shard of a 300*N-region sweep (weak scaling; chains are independent, no data-path
-collective) and the per-chain end-of-history smoothed states are gathered to rank 0 at the end of
-every step -- the path's only collective.
+A "step" is one pass of the hot path (forward EKF kernel, pinv grid, backward EKS kernel, scenario-scoring tail) over
+BASELINE.json's headline sweep: SIAlphaModelEKFOptControlled over 300 regions x 250 NPI-cost weights x (400 observed +
+120 horizon) days = 75 000 chains x 520 days = 39.0 M region-day EKF steps, all 11 reference outputs written (1376
+algorithmic bytes per region-day step).  Inputs are resident in HBM before the timed region.
+
+N > 1 (one process per GPU, torch.distributed over RCCL): the SAME fixed sweep is sharded by contiguous chain blocks
+(batch.shard_chains, 75 000 / N chains per rank) -- strong scaling, which is what BASELINE's "1 -> 8 GPU scaling" of
+the 300 x 400 x 250 sweep means.  Chains are independent, so there is no collective on the data path; at the end of
+every pass each rank's per-chain Pareto coordinates (J0, J1) -- 16 B per chain -- are gathered to rank 0, which filters
+the front per region (the path's only collective).  `--scaling weak` runs the round-1 variant instead (every rank a
+full 75 000-chain shard of a 300 N-region sweep).
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
 """
@@ -58,6 +61,11 @@ def parse():
                          "launch (epi_ekf_preferred_lane_block; default), n > 0 = blocks of n chains, 0 = classic [T][rows][B]")
     ap.add_argument("--no-score", action="store_true",
                     help="skip the scenario-scoring tail (SIalpha_Controlled + NPICost on the horizon) after each pass")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the fixed sweep sharded over the ranks (default); weak = every rank a full sweep "
+                         "of its own regions")
+    ap.add_argument("--shape", default="auto", choices=["auto", "lane", "quad"],
+                    help="lane mapping of the 6-state kernels (epi_batch_desc.shape): auto = by batch size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chains", type=int, default=0, help="0 = sized for ~15 s")
     return ap.parse_args()
@@ -66,7 +74,8 @@ def parse():
 def make_workload(args, rank):
     from epidemicmodeling_amd import synth
     if args.workload == "cfg4":
-        w = synth.make_cfg4(args.regions, args.eps, args.t_hist, args.horizon, region_offset=rank * args.regions)
+        w = synth.make_cfg4(args.regions, args.eps, args.t_hist, args.horizon,
+                            region_offset=rank * args.regions if args.scaling == "weak" else 0)
         name = (f"cfg4: SIAlphaModelEKFOptControlled sweep, {args.regions} regions x {args.eps} cost weights x "
                 f"({args.t_hist}+{args.horizon}) days")
     elif args.workload == "newcase":
@@ -187,10 +196,21 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     w, wname = make_workload(args, rank)
+    strong = args.scaling == "strong" and world > 1
+    B_total = w.B * (1 if (strong or world == 1) else world)
+    regions_total = w.Sx
+    if strong:
+        # the fixed sweep, sharded by contiguous chain blocks; every rank builds the same workload and
+        # keeps its own block of chains (and only the series those chains use)
+        if args.workload == "cfg3":
+            raise SystemExit("cfg3 (300 chains) does not shard: replicas only (DESIGN.md 6)")
+        lo, hi = batch.shard_chains(w.B, rank, world)
+        w = w.select(np.arange(lo, hi))
     m = w.m
     outputs = None if args.outputs == "all" else ["u_opt_smooth", "S_SMOOTH"]
     dw = batch.DeviceWorkload(w, dev)
-    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks, lane_block="auto" if args.lane_block < 0 else args.lane_block)
+    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks, lane_block="auto" if args.lane_block < 0 else args.lane_block,
+                             shape=args.shape)
     steps_per_pass = w.B * w.T
     t_hist_idx = w.meta.get("T_hist", w.T) - 1
 
@@ -229,9 +249,16 @@ def main():
             sp[0:3].copy_(runner.unblocked_at("S_SMOOTH", t_hist_idx)[0:3])
             sc = batch.score_sweep(runner.out["u_opt_smooth"], t_hist_idx + 1, sp, score_state["J0p"], score_state["J1p"], B=w.B)
             # Pareto-front filter + optimum per region (TrainPredictPrescribeNPI.m:624-633), still on the device
-            score_state["front"] = batch.pareto_front(sc["J0"], sc["J1"], w.Sx)
-            if world > 1:
-                batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
+            if strong:
+                # a region's 250 cost weights may straddle two ranks: (J0, J1) of all shards are gathered to rank 0
+                # (the path's only collective; shards padded to the common block length) and filtered there
+                allj = batch.gather_shards_to_root(torch.stack([sc["J0"], sc["J1"]]), B_total)
+                if rank == 0:
+                    score_state["front"] = batch.pareto_front(allj[0].contiguous(), allj[1].contiguous(), regions_total)
+            else:
+                score_state["front"] = batch.pareto_front(sc["J0"], sc["J1"], w.Sx)
+                if world > 1:
+                    batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
         elif world > 1:
             # no scoring: gather the per-chain smoothed state at the last observed day to rank 0
             batch.gather_to_root(runner.unblocked_at("S_SMOOTH", t_hist_idx).contiguous())
@@ -271,7 +298,7 @@ def main():
     ms_pinv = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
     ms_bwd = float(np.mean([e[2].elapsed_time(e[3]) for e in evs]))
     if rank == 0:
-        total_steps = steps_per_pass * world * args.steps
+        total_steps = (B_total * w.T if strong else steps_per_pass * world) * args.steps
         value = total_steps / elapsed
         full = args.outputs == "all"
         # algorithmic bytes per region-day step, split by kernel: eks_pinv produces no reference
@@ -293,13 +320,17 @@ def main():
             "metric": "region-day EKF steps/sec (300 regions x 400 days x 250 costs)",
             "value": value, "unit": "region-day EKF steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong" if (strong or world == 1) and args.scaling == "strong" else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "chunks": args.chunks,
-                       "lane_block": runner.blk,
+                       "lane_block": runner.blk, "shape": "quad (4 lanes per chain)" if runner.blk == 16 and m == 6 else "lane (1 lane per chain)",
+                       "sweep_chains_total": B_total,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),
                        "scoring_tail": bool(score),
-                       "parallelism": f"chains sharded over {world} GPU(s); end-of-sweep gather of (J0, J1) to rank 0"},
+                       "parallelism": (f"the fixed sweep's {B_total} chains sharded over {world} GPU(s) by contiguous blocks; "
+                                       "end-of-sweep gather of (J0, J1) to rank 0, Pareto filter there") if strong or world == 1 else
+                                      f"every rank its own full sweep ({world} x {w.B} chains); end-of-sweep gather of (J0, J1) to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          # what the kernel actually moves (PMC bytes of the committed profile / this run's duration):

@@ -183,6 +183,22 @@ def gather_to_root(t: torch.Tensor, group=None, dst: int = 0):
     return bufs
 
 
+def gather_shards_to_root(t: torch.Tensor, B_total: int, group=None, dst: int = 0):
+    """Strong-scaling form of the end-of-sweep gather: `t` [..., n_r] holds this rank's block of a chain-minor result whose
+    blocks come from shard_chains(B_total, rank, world) -- all of length ceil(B_total / world) except a shorter (possibly
+    empty) last one.  Blocks are padded to the common length, gathered to rank `dst` (one message per peer) and
+    reassembled there in chain order; returns the [..., B_total] tensor on `dst`, None elsewhere."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = (B_total + world - 1) // world
+    if t.shape[-1] < per:
+        t = torch.nn.functional.pad(t, (0, per - t.shape[-1]))
+    parts = gather_to_root(t.contiguous(), group=group, dst=dst)
+    if dist.get_rank(group) != dst:
+        return None
+    return torch.cat([p_.to(t.device) for p_ in parts], dim=-1)[..., :B_total]
+
+
 # ---------------------------------------------------------------------------
 # forward simulators (Tools/SIalpha_Controlled.m, Tools/SEIRP.m, Tools/NPICost.m) on the device
 # ---------------------------------------------------------------------------

@@ -53,3 +53,52 @@ def test_two_rank_shard_and_gather_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok, "gathered shards differ from the unsharded run"
+
+
+def _worker_strong(rank, world, port, q):
+    """bench.py's strong-scaling partition: the FIXED sweep cut into contiguous chain blocks with a ragged last shard
+    (3 regions x 5 cost weights = 15 chains over 2 ranks: 8 + 7; a region's cost weights straddle the two ranks), per-shard
+    results gathered with batch.gather_shards_to_root and reassembled on rank 0 in chain order."""
+    sys.path.insert(0, H.ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from epidemicmodeling_amd import batch, synth
+    w = synth.make_cfg4(3, 5, 30, 10)                  # 15 chains
+    lo, hi = batch.shard_chains(w.B, rank, world)
+    assert (lo, hi) == ((0, 8) if rank == 0 else (8, 15))
+    out = H.oracle_batch(w.select(np.arange(lo, hi)), n_threads=1)
+    res = torch.from_numpy(np.stack([out["S_SMOOTH"][29, 0], out["S_SMOOTH"][29, 2]]))     # [2, n_r]
+    full = batch.gather_shards_to_root(res, w.B)
+    if rank == 0:
+        ref = H.oracle_batch(w, n_threads=1)["S_SMOOTH"][29]
+        q.put(bool(full.shape == (2, 15) and np.array_equal(full.numpy(), np.stack([ref[0], ref[2]]))))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_strong_scaling_partition_with_ragged_last_shard_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_strong, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok, "reassembled shards differ from the unsharded run"
+
+
+def test_shard_chains_covers_every_chain_once():
+    from epidemicmodeling_amd import batch
+    for B in (1, 7, 15, 300, 75000):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [batch.shard_chains(B, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert all(0 <= lo <= hi <= B for lo, hi in cuts)
+    assert batch.shard_chains(75000, 7, 8) == (65625, 75000)
