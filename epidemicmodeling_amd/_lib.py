@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 ABI_VERSION = 2      # EPIEKF_ABI_VERSION of include/epiekf.h
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
-    "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
+    "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_ekf_run_host_multi", "epi_host_pool_release", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_npi_cost_device", "epi_si_controlled_device", "epi_si_controlled_host", "epi_sialpha_sim_host", "epi_seirp_sim_host", "epi_npi_cost_host", "epi_calib_copy_f64_device",
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
     "epi_preprocess_workspace_bytes", "epi_preprocess_device", "epi_nnls_affine_fit_device",
@@ -175,6 +175,9 @@ def lib():
         h.epi_nnls_affine_fit_device.argtypes = [C.POINTER(NnlsDesc)] + [C.c_void_p] * 7 + [C.c_void_p, C.c_char_p]
         h.epi_calib_copy_f64_device.restype = C.c_int
         h.epi_calib_copy_f64_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_char_p]
+        h.epi_ekf_run_host_multi.restype = C.c_int
+        h.epi_ekf_run_host_multi.argtypes = [C.POINTER(BatchDesc), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_char_p]
+        h.epi_host_pool_release.restype = None
         if h.epi_abi_version() != ABI_VERSION:
             raise ImportError("libepiekf.so ABI version mismatch")
         _lib = h

@@ -1266,62 +1266,229 @@ int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void 
     return EPI_OK;
 }
 
-int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, int device, char *err)
+// ---------------------------------------------------------------------------
+// host-pointer entry points: pooled contexts
+// ---------------------------------------------------------------------------
+// A context owns what a host call needs on one device -- a stream, a device arena and a pinned staging buffer -- and
+// outlives the call (idle contexts wait in a per-device pool), so that the 250 calls per region of the unchanged
+// reference caller (TrainPredictPrescribeNPI.m:421-460) do not pay 50 hipMalloc/hipFree and 50 synchronous copies each.
+}   // extern "C"
+#include <mutex>
+#include <thread>
+namespace epi {
+constexpr size_t kStageBytes = (size_t)64 << 20;
+struct HostCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char *arena = nullptr; size_t arena_bytes = 0;
+    char *pinned = nullptr;
+    ~HostCtx()
+    {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (arena) (void)hipFree(arena);
+        if (pinned) (void)hipHostFree(pinned);
+    }
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= arena_bytes) return hipSuccess;
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) return e;
+        if (arena) { (void)hipFree(arena); arena = nullptr; arena_bytes = 0; }
+        size_t want = bytes + bytes / 4;
+        e = hipMalloc((void **)&arena, want);
+        if (e != hipSuccess) { (void)hipGetLastError(); want = bytes; e = hipMalloc((void **)&arena, want); }
+        if (e != hipSuccess) { arena = nullptr; return e; }
+        arena_bytes = want;
+        return hipSuccess;
+    }
+};
+static std::mutex g_pool_mu;
+static std::vector<HostCtx *> g_pool;     // idle contexts of all devices
+static HostCtx *ctx_acquire(int device, hipError_t *e)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i]->device == device) { HostCtx *c = g_pool[i]; g_pool.erase(g_pool.begin() + (long)i); *e = hipSetDevice(device); return c; }
+    }
+    if ((*e = hipSetDevice(device)) != hipSuccess) return nullptr;
+    HostCtx *c = new HostCtx();
+    c->device = device;
+    if ((*e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { c->device = -1; delete c; return nullptr; }
+    if ((*e = hipHostMalloc((void **)&c->pinned, kStageBytes, hipHostMallocDefault)) != hipSuccess) { delete c; return nullptr; }
+    return c;
+}
+static void ctx_release(HostCtx *c)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(c);
+}
+
+// chains [lo, lo + n) of a host call on one context.  Per-chain arrays are [rows][B] in the caller's memory: the block is a
+// strided piece of each row.  Small calls are packed into the pinned buffer and moved by one copy each way.
+static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_inputs *in, const epi_outputs *out, int lo, int n, char *err)
+{
+    if (n <= 0) return EPI_OK;
+    epi_batch_desc d = *d0;
+    const int Bfull = d0->B;
+    d.B = n;
+    const bool id_x = !in->x_series, id_u = !in->u_series;      // identity series: one series per chain, sliced with the chains
+    if (id_x) d.Sx = n;
+    if (id_u) d.Su = n;
+    const int m = MODEL_TABLE[d.model].m, mm = m * m;
+    const size_t T = (size_t)d.T;
+    struct Piece { const void *host; void *host_out; size_t rows, width, pitch_host; size_t off; };   // rows x width bytes
+    std::vector<Piece> ins, outs;
+    size_t off = 0;
+    auto add = [&](std::vector<Piece> &v, const void *h, void *ho, size_t rows, size_t elem, size_t cols_full, size_t col0, size_t cols) -> size_t {
+        Piece p{h ? (const char *)h + col0 * elem : nullptr, ho ? (char *)ho + col0 * elem : nullptr, rows, cols * elem, cols_full * elem, off};
+        v.push_back(p);
+        const size_t o = off;
+        off += (rows * cols * elem + 255) & ~(size_t)255;
+        return o;
+    };
+    epi_inputs din{};
+    epi_outputs dout{};
+    // inputs
+    const size_t o_xs = in->x_series ? add(ins, in->x_series, nullptr, 1, 4, Bfull, lo, n) : 0;
+    const size_t o_us = in->u_series ? add(ins, in->u_series, nullptr, 1, 4, Bfull, lo, n) : 0;
+    const size_t o_x = id_x ? add(ins, in->x, nullptr, T, 8, Bfull, lo, n) : add(ins, in->x, nullptr, T, 8, d0->Sx, 0, d0->Sx);
+    const size_t o_u = id_u ? add(ins, in->u, nullptr, T * d.n_npi, 8, Bfull, lo, n) : add(ins, in->u, nullptr, T * d.n_npi, 8, d0->Su, 0, d0->Su);
+    size_t o_rs = 0, o_rc = 0;
+    if (d.r_mode == 1) o_rs = id_x ? add(ins, in->R_series, nullptr, T, 8, Bfull, lo, n) : add(ins, in->R_series, nullptr, T, 8, d0->Sx, 0, d0->Sx);
+    else o_rc = add(ins, in->R_scalar, nullptr, 1, 8, Bfull, lo, n);
+    const size_t o_prm = add(ins, in->prm, nullptr, EPI_PRM_COUNT, 8, Bfull, lo, n);
+    const size_t o_si = add(ins, in->s_init, nullptr, m, 8, Bfull, lo, n), o_pi = add(ins, in->Ps_init, nullptr, mm, 8, Bfull, lo, n);
+    const size_t o_sf = add(ins, in->s_final, nullptr, m, 8, Bfull, lo, n), o_pf = add(ins, in->Ps_final, nullptr, mm, 8, Bfull, lo, n);
+    const size_t o_q = add(ins, in->Q, nullptr, (d.q_mode ? T : (size_t)1) * mm, 8, Bfull, lo, n);
+    const size_t in_bytes = off;
+    // outputs
+    struct O { uint32_t bit; double *host; double **dev; size_t rows; };
+    const size_t rU = T * d.n_npi, rS = T * m, rP = T * mm, r1 = T;
+    O olist[] = {{EPI_OUT_U_OPT, out->u_opt, &dout.u_opt, rU}, {EPI_OUT_U_OPT_SMOOTH, out->u_opt_smooth, &dout.u_opt_smooth, rU},
+                 {EPI_OUT_S_MINUS, out->S_MINUS, &dout.S_MINUS, rS}, {EPI_OUT_S_PLUS, out->S_PLUS, &dout.S_PLUS, rS},
+                 {EPI_OUT_S_SMOOTH, out->S_SMOOTH, &dout.S_SMOOTH, rS}, {EPI_OUT_P_MINUS, out->P_MINUS, &dout.P_MINUS, rP},
+                 {EPI_OUT_P_PLUS, out->P_PLUS, &dout.P_PLUS, rP}, {EPI_OUT_P_SMOOTH, out->P_SMOOTH, &dout.P_SMOOTH, rP},
+                 {EPI_OUT_K_GAIN, out->K_GAIN, &dout.K_GAIN, rS}, {EPI_OUT_INNOVATIONS, out->innovations, &dout.innovations, r1},
+                 {EPI_OUT_RHO, out->rho, &dout.rho, r1}};
+    std::vector<size_t> o_out;
+    for (auto &o : olist)
+        o_out.push_back(((d.out_mask & o.bit) && o.host) ? add(outs, nullptr, o.host, o.rows, 8, Bfull, lo, n) : (size_t)-1);
+    const size_t o_rank = out->pinv_rank ? add(outs, nullptr, out->pinv_rank, T, 4, Bfull, lo, n) : (size_t)-1;
+    const size_t o_stat = out->status ? add(outs, nullptr, out->status, 1, 4, Bfull, lo, n) : (size_t)-1;
+    const size_t io_bytes = off;
+    const size_t wsb = epi_ekf_workspace_bytes(&d);
+    hipError_t e = cx->reserve(io_bytes + wsb + 256);
+    if (e != hipSuccess) return hip_fail(err, e, "device arena");
+    char *base = cx->arena;
+    din.x_series = in->x_series ? (const int32_t *)(base + o_xs) : nullptr;
+    din.u_series = in->u_series ? (const int32_t *)(base + o_us) : nullptr;
+    din.x = (const double *)(base + o_x); din.u = (const double *)(base + o_u);
+    din.R_series = d.r_mode == 1 ? (const double *)(base + o_rs) : nullptr;
+    din.R_scalar = d.r_mode == 1 ? nullptr : (const double *)(base + o_rc);
+    din.prm = (const double *)(base + o_prm);
+    din.s_init = (const double *)(base + o_si); din.Ps_init = (const double *)(base + o_pi);
+    din.s_final = (const double *)(base + o_sf); din.Ps_final = (const double *)(base + o_pf);
+    din.Q = (const double *)(base + o_q);
+    {
+        size_t k = 0;
+        for (auto &o : olist) { if (o_out[k] != (size_t)-1) *o.dev = (double *)(base + o_out[k]); k++; }
+    }
+    if (o_rank != (size_t)-1) dout.pinv_rank = (int32_t *)(base + o_rank);
+    if (o_stat != (size_t)-1) dout.status = (int32_t *)(base + o_stat);
+    void *ws = base + ((io_bytes + 255) & ~(size_t)255);
+    for (auto &p : ins)
+        if (!p.host) { set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG; }
+    const bool staged = io_bytes <= kStageBytes;
+    auto pack = [&](const Piece &p, char *dst) {       // caller's strided block -> contiguous rows
+        for (size_t r = 0; r < p.rows; r++) memcpy(dst + r * p.width, (const char *)p.host + r * p.pitch_host, p.width);
+    };
+    if (staged) {
+        for (auto &p : ins) pack(p, cx->pinned + p.off);
+        if ((e = hipMemcpyAsync(base, cx->pinned, in_bytes, hipMemcpyHostToDevice, cx->stream)) != hipSuccess) return hip_fail(err, e, "upload");
+    } else {
+        for (auto &p : ins)
+            if ((e = hipMemcpy2DAsync(base + p.off, p.width, p.host, p.pitch_host, p.width, p.rows, hipMemcpyHostToDevice, cx->stream)) != hipSuccess)
+                return hip_fail(err, e, "upload");
+    }
+    const int rc = epi_ekf_run_device(&d, &din, &dout, wsb ? ws : nullptr, wsb, cx->stream, err);
+    if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
+    if (staged) {
+        if (io_bytes > in_bytes &&
+            (e = hipMemcpyAsync(cx->pinned + in_bytes, base + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, cx->stream)) != hipSuccess)
+            return hip_fail(err, e, "download");
+        if ((e = hipStreamSynchronize(cx->stream)) != hipSuccess) return hip_fail(err, e, "kernel execution");
+        for (auto &p : outs)
+            for (size_t r = 0; r < p.rows; r++) memcpy((char *)p.host_out + r * p.pitch_host, cx->pinned + p.off + r * p.width, p.width);
+    } else {
+        for (auto &p : outs)
+            if ((e = hipMemcpy2DAsync(p.host_out, p.pitch_host, base + p.off, p.width, p.width, p.rows, hipMemcpyDeviceToHost, cx->stream)) != hipSuccess)
+                return hip_fail(err, e, "download");
+        if ((e = hipStreamSynchronize(cx->stream)) != hipSuccess) return hip_fail(err, e, "kernel execution");
+    }
+    return EPI_OK;
+}
+static int host_args_ok(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, char *err)
 {
     int rc = epi_ekf_validate(d, err);
     if (rc != EPI_OK) return rc;
     if (!in || !out) { set_err(err, "NULL inputs/outputs"); return EPI_ERR_BAD_ARG; }
-    if (lane_block_of(d) != d->B) { set_err(err, "epi_ekf_run_host takes the classic layout only (lane_block = 0)"); return EPI_ERR_UNSUPPORTED; }
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
-    const int m = MODEL_TABLE[d->model].m, mm = m * m;
-    const size_t B = d->B, T = d->T;
-    std::vector<void *> allocs;
-    auto fail = [&](hipError_t ee, const char *what) { for (void *p : allocs) (void)hipFree(p); return hip_fail(err, ee, what); };
-    auto up = [&](const void *h, size_t bytes, const void **dev) -> hipError_t {
-        *dev = nullptr;
-        if (!h || bytes == 0) return hipSuccess;
-        void *p; hipError_t ee = hipMalloc(&p, bytes);
-        if (ee != hipSuccess) return ee;
-        allocs.push_back(p); *dev = p;
-        return hipMemcpy(p, h, bytes, hipMemcpyHostToDevice);
-    };
-    epi_inputs din{};
-    epi_outputs dout{};
-#define UP(field, bytes) if ((e = up(in->field, (bytes), (const void **)&din.field)) != hipSuccess) return fail(e, "upload " #field)
-    UP(x_series, B * 4); UP(u_series, B * 4);
-    UP(x, T * d->Sx * 8); UP(u, T * d->n_npi * d->Su * 8);
-    if (d->r_mode == 1) { UP(R_series, T * d->Sx * 8); } else { UP(R_scalar, B * 8); }
-    UP(prm, (size_t)EPI_PRM_COUNT * B * 8);
-    UP(s_init, m * B * 8); UP(Ps_init, mm * B * 8); UP(s_final, m * B * 8); UP(Ps_final, mm * B * 8); UP(Q, (d->q_mode ? T : (size_t)1) * mm * B * 8);
-#undef UP
-    struct O { uint32_t bit; double *const *host; double **dev; size_t bytes; };
-    const size_t nU = T * d->n_npi * B * 8, nS = T * m * B * 8, nP = T * mm * B * 8, n1 = T * B * 8;
-    O outs[] = {{EPI_OUT_U_OPT, &out->u_opt, &dout.u_opt, nU}, {EPI_OUT_U_OPT_SMOOTH, &out->u_opt_smooth, &dout.u_opt_smooth, nU},
-                {EPI_OUT_S_MINUS, &out->S_MINUS, &dout.S_MINUS, nS}, {EPI_OUT_S_PLUS, &out->S_PLUS, &dout.S_PLUS, nS},
-                {EPI_OUT_S_SMOOTH, &out->S_SMOOTH, &dout.S_SMOOTH, nS}, {EPI_OUT_P_MINUS, &out->P_MINUS, &dout.P_MINUS, nP},
-                {EPI_OUT_P_PLUS, &out->P_PLUS, &dout.P_PLUS, nP}, {EPI_OUT_P_SMOOTH, &out->P_SMOOTH, &dout.P_SMOOTH, nP},
-                {EPI_OUT_K_GAIN, &out->K_GAIN, &dout.K_GAIN, nS}, {EPI_OUT_INNOVATIONS, &out->innovations, &dout.innovations, n1},
-                {EPI_OUT_RHO, &out->rho, &dout.rho, n1}};
-    for (auto &o : outs)
-        if ((d->out_mask & o.bit) && *o.host) {
-            void *p; if ((e = hipMalloc(&p, o.bytes)) != hipSuccess) return fail(e, "hipMalloc output");
-            allocs.push_back(p); *o.dev = (double *)p;
-        }
-    if (out->pinv_rank) { void *p; if ((e = hipMalloc(&p, T * B * 4)) != hipSuccess) return fail(e, "hipMalloc"); allocs.push_back(p); dout.pinv_rank = (int32_t *)p; }
-    if (out->status) { void *p; if ((e = hipMalloc(&p, B * 4)) != hipSuccess) return fail(e, "hipMalloc"); allocs.push_back(p); dout.status = (int32_t *)p; }
-    void *ws = nullptr;
-    const size_t wsb = epi_ekf_workspace_bytes(d);
-    if (wsb) { if ((e = hipMalloc(&ws, wsb)) != hipSuccess) return fail(e, "hipMalloc workspace"); allocs.push_back(ws); }
-    rc = epi_ekf_run_device(d, &din, &dout, ws, wsb, nullptr, err);
-    if (rc != EPI_OK) { for (void *p : allocs) (void)hipFree(p); return rc; }
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "kernel execution");
-    for (auto &o : outs)
-        if (*o.dev && (e = hipMemcpy(*o.host, *o.dev, o.bytes, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
-    if (dout.pinv_rank && (e = hipMemcpy(out->pinv_rank, dout.pinv_rank, T * B * 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
-    if (dout.status && (e = hipMemcpy(out->status, dout.status, B * 4, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "download");
-    for (void *p : allocs) (void)hipFree(p);
+    if (lane_block_of(d) != d->B) { set_err(err, "the host entry points take the classic layout only (lane_block = 0)"); return EPI_ERR_UNSUPPORTED; }
+    if (d->storage != 0) { set_err(err, "the host entry points return fp64 arrays (storage = 0)"); return EPI_ERR_UNSUPPORTED; }
+    if (!in->x_series && d->Sx != d->B) { set_err(err, "identity x_series needs Sx == B"); return EPI_ERR_BAD_ARG; }
+    if (!in->u_series && d->Su != d->B) { set_err(err, "identity u_series needs Su == B"); return EPI_ERR_BAD_ARG; }
     return EPI_OK;
+}
+}   // namespace epi
+extern "C" {
+
+int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, int device, char *err)
+{
+    int rc = host_args_ok(d, in, out, err);
+    if (rc != EPI_OK) return rc;
+    hipError_t e = hipSuccess;
+    HostCtx *cx = ctx_acquire(device, &e);
+    if (!cx || e != hipSuccess) { if (cx) ctx_release(cx); return hip_fail(err, e, "hipSetDevice / context"); }
+    rc = run_host_block(cx, d, in, out, 0, d->B, err);
+    ctx_release(cx);
+    return rc;
+}
+
+int epi_ekf_run_host_multi(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, int n_devices,
+                           const int *device_ids, char *err)
+{
+    int rc = host_args_ok(d, in, out, err);
+    if (rc != EPI_OK) return rc;
+    if (n_devices < 1 || n_devices > 64) { set_err(err, "n_devices must be 1..64"); return EPI_ERR_BAD_ARG; }
+    const int per = (d->B + n_devices - 1) / n_devices;
+    std::vector<int> rcs((size_t)n_devices, EPI_OK);
+    std::vector<std::vector<char>> errs((size_t)n_devices, std::vector<char>(256, 0));
+    std::vector<std::thread> th;
+    for (int r = 0; r < n_devices; r++) {
+        const int lo = r * per < d->B ? r * per : d->B, n = (lo + per <= d->B ? per : d->B - lo);
+        const int dev = device_ids ? device_ids[r] : r;
+        th.emplace_back([=, &rcs, &errs]() {
+            if (n <= 0) return;
+            hipError_t e = hipSuccess;
+            HostCtx *cx = ctx_acquire(dev, &e);
+            if (!cx || e != hipSuccess) { if (cx) ctx_release(cx); rcs[(size_t)r] = hip_fail(errs[(size_t)r].data(), e, "hipSetDevice / context"); return; }
+            rcs[(size_t)r] = run_host_block(cx, d, in, out, lo, n, errs[(size_t)r].data());
+            ctx_release(cx);
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r = 0; r < n_devices; r++)
+        if (rcs[(size_t)r] != EPI_OK) { set_err(err, errs[(size_t)r].data()); return rcs[(size_t)r]; }
+    return EPI_OK;
+}
+
+void epi_host_pool_release(void)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (HostCtx *c : g_pool) delete c;
+    g_pool.clear();
 }
 
 int epi_calib_copy_f64_device(const double *src, double *dst, size_t n, void *stream, char *err)

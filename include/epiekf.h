@@ -184,10 +184,26 @@ int epi_ekf_preferred_lane_block(const epi_batch_desc *d);
 int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
                        void *workspace, size_t workspace_bytes, void *stream, char *err);
 
-/* Same call on HOST pointers: allocates device buffers, copies in, runs, copies
- * the selected outputs back and synchronises (what a MEX gateway calls). */
+/* Same call on HOST pointers (what a MEX gateway calls): copies in, runs, copies the selected outputs back and
+ * synchronises.  Replaces one call of Tools/SIAlphaModelEKF.m:1 (B = 1) or a whole loop of them
+ * (Tools/TrainPredictPrescribeNPI.m:421-460, B = 250 cost weights).  Classic layout only (lane_block = 0).
+ * Device memory, a pinned staging buffer and a stream come from a per-device pool of contexts that lives as long as the
+ * library (no hipMalloc / hipFree per call after the first): a call whose inputs + outputs fit the staging buffer
+ * (64 MiB) moves them with ONE host-to-device and ONE device-to-host copy.  Thread-safe. */
 int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
                      int device, char *err);
+
+/* The same on SEVERAL GPUs of the node: the B chains are cut into n_devices contiguous blocks
+ * (block r = chains [r * ceil(B / n_devices), ...), a shorter or empty last block), one host thread per block uploads
+ * its chains, runs them on device_ids[r] (NULL: devices 0 .. n_devices-1) and writes the out_mask-selected outputs
+ * straight into the caller's arrays -- chains are independent, so there is no exchange between the devices; this is the
+ * loop over regions / cost weights of Tools/TrainPredictPrescribeNPI.m:93,421 spread over the GPUs.  A device may be
+ * named more than once (two blocks then share it).  Returns the first error of any block. */
+int epi_ekf_run_host_multi(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
+                           int n_devices, const int *device_ids, char *err);
+
+/* Frees every pooled context (device arenas, pinned buffers, streams).  Optional: call before unloading the library. */
+void epi_host_pool_release(void);
 
 /* ---- forward simulators and cost (Tools/SIalpha_Controlled.m, SEIRP.m, NPICost.m) ---- */
 typedef struct epi_sim_desc {

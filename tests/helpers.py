@@ -179,3 +179,45 @@ def lapack_reading_worker(job):
         nd = numpy_chain(w, int(c))
         out.append({k: np.asarray(nd[k]) for k in ("S_MINUS", "S_PLUS", "S_SMOOTH", "u_opt_smooth", "pinv_rank")})
     return out
+
+
+def host_call(w, devices=None, outputs=None, extras=True, shape=0):
+    """Workload `w` through the HOST-pointer C ABI (classic layout, numpy arrays [T][rows][B]): epi_ekf_run_host on device
+    0, or -- devices = list of device ids -- epi_ekf_run_host_multi with one chain block per entry.  Returns dict of arrays."""
+    import ctypes as C
+    from epidemicmodeling_amd import _lib
+    names = [n for n in (outputs or OUT_NAMES) if not (w.model.startswith("NewCase") and n == "u_opt_smooth")]
+    m, n_npi, B, T = w.m, w.n_npi, w.B, w.T
+    rows = {"u_opt": n_npi, "u_opt_smooth": n_npi, "S_MINUS": m, "S_PLUS": m, "S_SMOOTH": m, "P_MINUS": m * m, "P_PLUS": m * m,
+            "P_SMOOTH": m * m, "K_GAIN": m}
+    out = {k: np.full((T, rows[k], B) if k in rows else (T, B), np.nan) for k in names}
+    mask = 0
+    for k in names:
+        mask |= L.OUT_BITS[k]
+    Sx = w.x.shape[1]; Su = w.u.shape[2]
+    d = _lib.make_desc(w.model, B, T, Sx, Su, n_npi, w.L, w.order, w.obs_type, 1 if w.R_series is not None else 0, mask,
+                       1 if np.ndim(w.Q) == 3 else 0)
+    d.shape = shape
+    ins, outs = _lib.Inputs(), _lib.Outputs()
+    keep = []
+    def ptr(a, dt=np.float64):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+        return a.ctypes.data
+    ins.x_series, ins.u_series = ptr(w.x_series, np.int32), ptr(w.u_series, np.int32)
+    ins.x, ins.u, ins.R_series, ins.R_scalar, ins.prm = ptr(w.x), ptr(w.u), ptr(w.R_series), ptr(w.R_scalar), ptr(w.prm)
+    ins.s_init, ins.Ps_init, ins.s_final, ins.Ps_final, ins.Q = ptr(w.s_init), ptr(w.Ps_init), ptr(w.s_final), ptr(w.Ps_final), ptr(w.Q)
+    for k in names:
+        setattr(outs, k, out[k].ctypes.data)
+    if extras:
+        out["pinv_rank"] = np.full((T, B), -7, dtype=np.int32); out["status"] = np.full((B,), -7, dtype=np.int32)
+        outs.pinv_rank, outs.status = out["pinv_rank"].ctypes.data, out["status"].ctypes.data
+    err = C.create_string_buffer(256)
+    if devices is None:
+        rc = _lib.lib().epi_ekf_run_host(C.byref(d), C.byref(ins), C.byref(outs), 0, err)
+    else:
+        ids = (C.c_int * len(devices))(*devices)
+        rc = _lib.lib().epi_ekf_run_host_multi(C.byref(d), C.byref(ins), C.byref(outs), len(devices), ids, err)
+    _lib.check(rc, err)
+    return out
