@@ -161,7 +161,7 @@ def _run(model, u, x, params, s_init, Ps_init, s_final, Ps_final, w_bar, v_bar, 
     for n_ in names:
         setattr(outs, n_, out[n_].ctypes.data)
     err = C.create_string_buffer(256)
-    rc = _lib.lib().epi_ekf_run_host(C.byref(desc), C.byref(ins), C.byref(outs), int(device), err)
+    rc = _lib.lib().epi_ekf_run_host(C.byref(desc), C.byref(ins), C.byref(outs), _dev_index(device), err)
     _lib.check(rc, err)
     del keep
     S = lambda n_: np.asfortranarray(out[n_][:, :, 0].T)
@@ -265,7 +265,7 @@ def Rt_ExpFitEKF(x, s_init, params, w_bar, v_bar, Ps_init, Q_w, R_v, beta, gamma
     for n in rows:
         setattr(outs, n, out[n].ctypes.data)
     err = C.create_string_buffer(256)
-    rc = _lib.lib().epi_rt_expfit_run_host(C.byref(d), None, x.ctypes.data, rp.ctypes.data, C.byref(outs), int(device), err)
+    rc = _lib.lib().epi_rt_expfit_run_host(C.byref(d), None, x.ctypes.data, rp.ctypes.data, C.byref(outs), _dev_index(device), err)
     _lib.check(rc, err)
     S = lambda n: np.asfortranarray(out[n][:, :, 0].T)
     P = lambda n: np.asfortranarray(out[n][:, :, 0].reshape(T, 2, 2).transpose(2, 1, 0))

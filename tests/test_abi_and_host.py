@@ -214,20 +214,11 @@ def test_rt_expfit_validate_and_tools_errors(hip_lib):
         tools.Rt_ExpFitEKF(np.ones((1, 5)), [1.0, 0.0], [1, 0.9], [0, 0], 0, np.eye(2), np.eye(2), 1.0, 0.9, 0.995, 21, 1)
 
 
-def test_mex_gateways_compile_against_the_abi_header():
-    """matlab/*.cpp are shipped as source (no MATLAB in the build image): at least they must be valid C++ against
-    include/epiekf.h and the documented MEX API signatures (tests/mex_stub/mex.h is a declarations-only stand-in)."""
+def test_plain_c_consumers_see_the_same_header():
+    """include/epiekf.h is valid C99 (the MEX gateways themselves are compiled, linked and executed by
+    tests/test_mex_boundary.py)."""
     import shutil
     import subprocess
-    cxx = shutil.which("g++")
-    if not cxx:
-        pytest.skip("no g++")
-    for f in ("epiekf_mex.cpp", "epiekf_rt_mex.cpp", "epiekf_batch_mex.cpp", "epiekf_sim_mex.cpp"):
-        r = subprocess.run([cxx, "-std=c++11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
-                            "-I" + os.path.join(H.ROOT, "tests", "mex_stub"), "-I" + os.path.join(H.ROOT, "include"),
-                            os.path.join(H.ROOT, "matlab", f)], capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
-    # plain C consumers see the same header
     r = subprocess.run([shutil.which("gcc") or "gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror",
                         "-I" + os.path.join(H.ROOT, "include"), "-x", "c", "-"], input='#include "epiekf.h"\nint main(void){epi_batch_desc d; d.lane_block = 0; return d.lane_block + (int)sizeof(epi_outputs) * 0;}\n',
                        capture_output=True, text=True)
