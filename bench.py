@@ -66,6 +66,9 @@ def parse():
                          "of its own regions")
     ap.add_argument("--shape", default="auto", choices=["auto", "lane", "quad"],
                     help="lane mapping of the 6-state kernels (epi_batch_desc.shape): auto = by batch size")
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
+                    help="f32 = BASELINE config 5's fp32: outputs STORED as float32, arithmetic and the smoother's inputs fp64 "
+                         "(SURVEY.md 0: fp32 covariance arithmetic is not viable at cond(P) up to 1e8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chains", type=int, default=0, help="0 = sized for ~15 s")
     return ap.parse_args()
@@ -210,7 +213,7 @@ def main():
     outputs = None if args.outputs == "all" else ["u_opt_smooth", "S_SMOOTH"]
     dw = batch.DeviceWorkload(w, dev)
     runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks, lane_block="auto" if args.lane_block < 0 else args.lane_block,
-                             shape=args.shape)
+                             shape=args.shape, storage=args.storage)
     steps_per_pass = w.B * w.T
     t_hist_idx = w.meta.get("T_hist", w.T) - 1
 
@@ -305,6 +308,9 @@ def main():
         # output of its own -- its algorithmic bytes are the P_MINUS it must read (m*m doubles)
         alg = {"ekf_fwd": BYTES_FWD[m] if full else 112, "eks_pinv": 8 * m * m,
                "eks_bwd": BYTES_BWD[m] if full else 8 * (m + 12)}
+        if args.storage == "f32":       # outputs are 4-byte elements; the inputs x, u, R stay fp64 (112 B)
+            alg["ekf_fwd"] = 112 + (alg["ekf_fwd"] - 112) // 2
+            alg["eks_bwd"] //= 2
         if w.model.startswith("NewCase"):     # no u_opt_smooth output, no separate pinv stage (mrdivide inline)
             alg["eks_bwd"] = 8 * (m + m * m) if full else 8 * m
             alg["eks_pinv"] = 0
@@ -312,7 +318,7 @@ def main():
         dom = max(ms, key=ms.get)
         dom_bytes = alg[dom] * steps_per_pass
         achieved = dom_bytes / (ms[dom] * 1e-3) / 1e9
-        step_bytes = (BYTES_PER_STEP_FULL[m] if full else 112 + 8 * (m + 12)) * steps_per_pass
+        step_bytes = (alg["ekf_fwd"] + alg["eks_bwd"]) * steps_per_pass
         step_gbs = step_bytes / (sum(ms.values()) * 1e-3) / 1e9
         traffic = pmc_traffic(dom, args)
         copy_bw = measured_copy_bandwidth(dev)
@@ -321,8 +327,8 @@ def main():
             "value": value, "unit": "region-day EKF steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (strong or world == 1) and args.scaling == "strong" else "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "chunks": args.chunks,
+            "vs_baseline": None, "dtype": "f64" if args.storage == "f64" else "f64 arithmetic, f32 storage", "data": "synthetic",
+            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "chunks": args.chunks,
                        "lane_block": runner.blk, "shape": "quad (4 lanes per chain)" if runner.blk == 16 and m == 6 else "lane (1 lane per chain)",
                        "sweep_chains_total": B_total,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,

@@ -61,7 +61,8 @@ class DeviceWorkload:
 class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
-    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True, lane_block=0, shape=0):
+    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True, lane_block=0, shape=0,
+                 storage="f64"):
         """chunks > 1: a full run() is split into that many chain chunks on helper streams (overlaps the
         (chain, step)-parallel pinv grid with the sequential kernels of the other chunks).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
@@ -78,6 +79,9 @@ class EkfRunner:
                                    dw.r_mode, self.mask, dw.q_mode)
         # epi_batch_desc.shape: 0 = by batch size, 1 = one lane per chain, 2 = four lanes per chain (6-state generic models)
         self.desc.shape = {"auto": 0, "lane": 1, "quad": 2}.get(shape, shape)
+        # epi_batch_desc.storage: "f32" = outputs stored as float32 (each the fp64 result rounded once; BASELINE config 5)
+        self.desc.storage = {"f64": 0, "f32": 1}[storage]
+        odt = torch.float32 if storage == "f32" else torch.float64
         if lane_block == "auto":       # one block per wavefront of the launch
             lane_block = int(_lib.lib().epi_ekf_preferred_lane_block(C.byref(self.desc)))
         self.blk = dw.B if (lane_block <= 0 or lane_block >= dw.B) else int(lane_block)
@@ -94,7 +98,7 @@ class EkfRunner:
                 shape = (dw.T, dw.B) if rows == 0 else (dw.T, rows, dw.B)
             else:
                 shape = (dw.T, self.nblk * self.blk) if rows == 0 else (dw.T, self.nblk, rows, self.blk)
-            self.out[n] = torch.empty(shape, dtype=torch.float64, device=dev)
+            self.out[n] = torch.empty(shape, dtype=odt, device=dev)
         self.pinv_rank = torch.empty((dw.T, self.nblk * self.blk), dtype=torch.int32, device=dev) if extras else None
         self.status = torch.zeros((dw.B,), dtype=torch.int32, device=dev) if extras else None
         self.ws_bytes = int(h.epi_ekf_workspace_bytes(C.byref(self.desc)))
@@ -145,13 +149,13 @@ class EkfRunner:
         return x.permute(1, 0, 2).reshape(rows, nb * blk)[:, :self.dw.B]
 
     def output_bytes(self) -> int:
-        return sum(t.numel() * 8 for t in self.out.values())
+        return sum(t.numel() * t.element_size() for t in self.out.values())
 
 
-def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True, lane_block=0, shape=0):
+def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True, lane_block=0, shape=0, storage="f64"):
     """Convenience: upload `w`, run once, return dict name -> numpy array [T, rows, B] (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
-    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck, lane_block=lane_block, shape=shape)
+    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck, lane_block=lane_block, shape=shape, storage=storage)
     r.run()
     torch.cuda.synchronize(dw.device)
     res = {n: r.unblocked(n).cpu().numpy() for n in r.out}

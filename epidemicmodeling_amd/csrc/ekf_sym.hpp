@@ -49,6 +49,17 @@ EPI_DEV void store_sym(double *__restrict__ dst, int t, const Lay &l, const doub
         for (int i = 0; i < M; i++) bst(r, voff, (unsigned)IXM(i, j) * rowb, P[sidx(i, j)]);
 }
 template <int M>
+EPI_DEV void store_sym_f32(float *__restrict__ dst, int t, const Lay &l, const double (&P)[nsym<M>()])
+{
+    if (!dst) return;
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice_f32(dst, t, M * M, l, voff, rowb);
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i < M; i++) bst32(r, voff, (unsigned)IXM(i, j) * rowb, P[sidx(i, j)]);
+}
+template <int M>
 EPI_DEV void load_sym(const double *__restrict__ src, int t, const Lay &l, double (&P)[nsym<M>()])
 {
     unsigned voff, rowb;
@@ -193,7 +204,7 @@ EPI_DEV void predict_cov_sym(const double (&A)[M * M], const double (&Pp)[M * (M
 //         waves fit a CU AND an eks_pinv wave (168 VGPRs, no LDS) fits beside each of them: the pipelined launch
 //         (epi_batch_desc.chunks = -2) runs one half's eks_pinv grid in the issue slots the other half's forward waves
 //         leave idle.
-template <int M, int FLIP, int LP>
+template <int M, int FLIP, int LP, int STOR = 0>
 __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
     extern __shared__ double lds[];   // three sliding windows [3][L][stride], one column per lane (+ [48][stride], LP)
@@ -257,6 +268,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
 
         store_vec<M>(a.S_MINUS, t, lay, sk_minus);
         store_sym<M>(a.P_MINUS, t, lay, Pm, (a.ws_upper & 1) != 0);
+        if (STOR) { store_rows_f32<M>(a.f.S_MINUS, t, M, lay, sk_minus); store_sym_f32<M>(a.f.P_MINUS, t, lay, Pm); }
 
         double C[M];
         obs_jacobian<M>(a.mf, sk_minus, C);                 // C(4:6) == 0 for m = 6
@@ -331,6 +343,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         for (int q = 0; q < kNpi; q++) u_app[q] = u_in[q];
         nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
         store_u(a.u_opt, a, t, lay, u_app);
+        if (STOR) store_rows_f32<kNpi>(a.f.u_opt, t, (unsigned)a.n_npi, lay, u_app);
         {
             double A[M * M];
             state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
@@ -342,6 +355,10 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         store_sym<M>(a.P_PLUS, t, lay, Pp, (a.ws_upper & 2) != 0);
         store_vec<M>(a.K_GAIN, t, lay, K);
         if (a.innovations) a.innovations[lay_scalar(t, lay)] = innov;
+        if (STOR) {
+            store_rows_f32<M>(a.f.S_PLUS, t, M, lay, sk_plus); store_sym_f32<M>(a.f.P_PLUS, t, lay, Pp);
+            store_rows_f32<M>(a.f.K_GAIN, t, M, lay, K); store_scalar_f32(a.f.innovations, t, lay, innov);
+        }
 
         // innovation monitor (identical to ekf_fwd)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
@@ -357,6 +374,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         // rho keeps FILTER-step order also for the time-flipped wrappers: GenericEKF.m:233 squeezes it to T x 1 and
         // Backward*.m:40 reverses a third dimension of size 1, i.e. nothing
         if (a.rho) a.rho[lay_scalar(k, lay)] = sumN / (double)cnt;
+        if (STOR) store_scalar_f32(a.f.rho, k, lay, sumN / (double)cnt);
         if (fixed_R) {
             if (beta != 1.0 && valid && k < T - 1) {
                 const double sumC = ring_sum(winCov, head, L, cc, stride);
@@ -376,7 +394,7 @@ struct BwdIn {   // everything smoother step k reads: forward quantities of step
     double Sp[M], Pp[M * (M + 1) / 2], u[kNpi], X[M * M];
     int rk;
 };
-template <int M, int FLIP>
+template <int M, int FLIP, int STOR = 0>
 __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
     __shared__ double vlds[4 * kNpi * kWave];   // a, u_min, u_max, w: one column per lane
@@ -423,11 +441,13 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         }
     store_vec<M>(a.S_SMOOTH, tT, lay, Ss);
     store_sym<M>(a.P_SMOOTH, tT, lay, Ps);
-    if (a.u_opt_smooth) {
+    if (STOR) { store_rows_f32<M>(a.f.S_SMOOTH, tT, M, lay, Ss); store_sym_f32<M>(a.f.P_SMOOTH, tT, lay, Ps); }
+    if (a.u_opt_smooth || (STOR && a.f.u_opt_smooth)) {
         double z[kNpi];
 #pragma unroll
         for (int k = 0; k < kNpi; k++) z[k] = 0.0;
         store_u(a.u_opt_smooth, a, tT, lay, z);
+        if (STOR) store_rows_f32<kNpi>(a.f.u_opt_smooth, tT, (unsigned)a.n_npi, lay, z);
     }
     if (a.pinv_rank) a.pinv_rank[lay_scalar(tT, lay)] = -1;
 
@@ -459,6 +479,10 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         store_vec<M>(a.S_SMOOTH, t_pend, lay, Ss);
         store_sym<M>(a.P_SMOOTH, t_pend, lay, Ps);
         if (a.u_opt_smooth) store_u(a.u_opt_smooth, a, t_pend, lay, u_pend);
+        if (STOR) {
+            store_rows_f32<M>(a.f.S_SMOOTH, t_pend, M, lay, Ss); store_sym_f32<M>(a.f.P_SMOOTH, t_pend, lay, Ps);
+            store_rows_f32<kNpi>(a.f.u_opt_smooth, t_pend, (unsigned)a.n_npi, lay, u_pend);
+        }
     };
 
     // double buffering: the inputs of step k-1 are requested at the top of step k (ahead of the stores of step k+1's
@@ -573,7 +597,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         for (int i = 0; i < M; i++) Ss[i] = Sn[i];
 #pragma unroll
         for (int q = 0; q < kNpi; q++) u_pend[q] = cur.u[q];
-        if (a.u_opt_smooth) {                                  // :229
+        if (a.u_opt_smooth || (STOR && a.f.u_opt_smooth)) {    // :229
             double sn_unused[M];
             nlin_state_update<M, FLIP>(p, a.mf, u_pend, Ss, sn_unused);
         }

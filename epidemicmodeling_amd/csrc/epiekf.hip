@@ -60,6 +60,11 @@ struct KArgs {
     // bound by HBM / per-CU memory throughput, which scales with active lanes, not by wave count.
     int lw;
     int quad;   // 6-state generic models: four lanes per chain (ekf_quad.hpp) instead of one
+    // epi_batch_desc.storage = 1: the caller's outputs are fp32 arrays (same layouts, 4-byte elements); each selected
+    // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
+    // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
+    int stor;   // 1: fp32 storage (see F32 below)
+    struct F32 { float *u_opt, *u_opt_smooth, *S_MINUS, *S_PLUS, *S_SMOOTH, *P_MINUS, *P_PLUS, *P_SMOOTH, *K_GAIN, *innovations, *rho; } f;
 };
 
 // position in the caller's time axis of filter step k (flipped wrappers run the
@@ -200,6 +205,33 @@ EPI_DEV void store_u(double *__restrict__ dst, const KArgs &a, int t, const Lay 
 #pragma unroll
     for (int k = 0; k < kNpi; k++)
         if (k < a.n_npi) bst(r, voff, (unsigned)k * rowb, u[k]);
+}
+
+// fp32-storage twins of the stores above (epi_batch_desc.storage = 1): same layout formulas with 4-byte elements, the
+// value rounded once from the fp64 register
+EPI_DEV rsrc_t lay_slice_f32(const float *p, int t, unsigned rows, const Lay &l, unsigned &voff, unsigned &rowb)
+{
+    rowb = l.blk * 4u;
+    voff = (l.cb * rows * l.blk + l.cr) * 4u;
+    return mk_rsrc(p + (size_t)t * rows * l.bp, rows * l.bp * 4u);
+}
+EPI_DEV void bst32(rsrc_t r, unsigned voff, unsigned soff, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, voff, soff, 0);
+}
+template <int N>
+EPI_DEV void store_rows_f32(float *__restrict__ dst, int t, unsigned rows, const Lay &l, const double (&v)[N])
+{
+    if (!dst) return;
+    unsigned voff, rowb;
+    const rsrc_t r = lay_slice_f32(dst, t, rows, l, voff, rowb);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        if ((unsigned)i < rows) bst32(r, voff, (unsigned)i * rowb, v[i]);
+}
+EPI_DEV void store_scalar_f32(float *__restrict__ dst, int t, const Lay &l, double v)
+{
+    if (dst) dst[lay_scalar(t, l)] = (float)v;
 }
 
 // ---------------------------------------------------------------------------
@@ -773,10 +805,12 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     WsLayout w{};
     size_t off = 0;
     auto take = [&](bool need, size_t n) { size_t o = off; if (need) off += (n + 255) & ~(size_t)255; return o; };
-    w.s_minus = take(!(d->out_mask & EPI_OUT_S_MINUS), nS);
-    w.s_plus = take(!(d->out_mask & EPI_OUT_S_PLUS), nS);
-    w.p_minus = take(!(d->out_mask & EPI_OUT_P_MINUS), nP);
-    w.p_plus = take(!(d->out_mask & EPI_OUT_P_PLUS), nP);
+    // fp32 storage: the forward quantities the smoother reads back are fp64 workspace whatever the caller selected
+    const uint32_t om = d->storage ? (d->out_mask & ~(uint32_t)(EPI_OUT_S_MINUS | EPI_OUT_S_PLUS | EPI_OUT_P_MINUS | EPI_OUT_P_PLUS)) : d->out_mask;
+    w.s_minus = take(!(om & EPI_OUT_S_MINUS), nS);
+    w.s_plus = take(!(om & EPI_OUT_S_PLUS), nS);
+    w.p_minus = take(!(om & EPI_OUT_P_MINUS), nP);
+    w.p_plus = take(!(om & EPI_OUT_P_PLUS), nP);
     // smoother intermediates of the generic models: X = pinv(P_MINUS) and its rank word per (step, chain)
     const bool generic = MODEL_TABLE[d->model].generic;
     w.x = take(generic, (size_t)d->T * (m * (m + 1) / 2) * Bp * sizeof(double));   // packed upper triangle of X
@@ -941,7 +975,8 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
             // instead of 408 VGPRs (a third of the AGPR traffic), still four workgroups per CU
             const size_t per_lane = ((size_t)3 * ka.L + 4 * kNpi) * sizeof(double);
             const bool lp = M == 6 && ka.lw <= kPipeLanes && per_lane * kPipeLanes * 4 <= 160u * 1024u && !getenv("EPIEKF_NO_LP");
-            if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), per_lane * kPipeLanes, st, ka, ka.dense_flag);
+            if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
+            else if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), per_lane * kPipeLanes, st, ka, ka.dense_flag);
             else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
@@ -957,7 +992,8 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
     }
     if (phase == 0 || phase == 2 || phase == 4) {
         if (run_sym) {
-            hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+            if (ka.stor) hipLaunchKernelGGL((eks_bwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+            else hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (run_dense) {
@@ -980,6 +1016,9 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
             if (e != hipSuccess) return e;
             if (GENERIC) {
                 e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP, 0>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+                if (e != hipSuccess) return e;
+                e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP, 0, 1>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
                 if (e != hipSuccess) return e;
             }
@@ -1019,7 +1058,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
         }
         return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
     }
-    if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1 && !ka.quad) {
+    if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1 && !ka.quad && !ka.stor) {
         // Pipelined halves.  The forward kernel of the second half and the eks_pinv grid of the first half are in flight
         // together, and -- because this forward variant (LDS-resident model constants, LDS sized by the lanes used)
         // needs 298 VGPRs and eks_pinv 168 -- they share SIMDs: the VALU-bound Jacobi runs in the issue slots the
@@ -1148,7 +1187,7 @@ int epi_ekf_preferred_lane_block(const epi_batch_desc *d)
     probe = *d; probe.lane_block = 0;
     if (epi_ekf_validate(&probe, nullptr) != EPI_OK) return 0;
     const ModelInfo &mi = MODEL_TABLE[d->model];
-    const int lw = use_quad(d->shape, mi.m, mi.generic != 0, d->B) ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2);
+    const int lw = (!d->storage && use_quad(d->shape, mi.m, mi.generic != 0, d->B)) ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2);
     return lw < d->B ? lw : d->B;
 }
 
@@ -1170,13 +1209,23 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     if (wl.total > 0 && (!workspace || workspace_bytes < wl.total)) {
         set_err(err, epi_status_string(EPI_ERR_WORKSPACE)); return EPI_ERR_WORKSPACE;
     }
-    const uint32_t om = d->out_mask;
+    const bool f32 = d->storage == 1;
+    if (f32 && (!mi.generic || d->q_mode != 0 || d->path_hint != 1)) {
+        set_err(err, "storage = 1 (fp32) runs the packed kernels of the generic models only: fixed Q_w and path_hint = 1 "
+                     "(epi_ekf_precheck_device said the batch qualifies)");
+        return EPI_ERR_UNSUPPORTED;
+    }
+    // fp32 storage: every fp64 output pointer the kernels see is either workspace (forward quantities) or NULL
+    const uint32_t om = f32 ? 0u : d->out_mask;
+    const uint32_t om32 = f32 ? d->out_mask : 0u;
     auto sel = [&](uint32_t bit, double *p) -> double * { return (om & bit) ? p : nullptr; };
+    auto sel32 = [&](uint32_t bit, double *p) -> float * { return (om32 & bit) ? (float *)p : nullptr; };
     char *ws = (char *)workspace;
     KArgs ka{};
     ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode; ka.q_mode = d->q_mode;
     ka.blk = lane_block_of(d); ka.nblk = (d->B + ka.blk - 1) / ka.blk;
-    ka.quad = use_quad(d->shape, mi.m, mi.generic != 0, d->B) ? 1 : 0;
+    ka.quad = (!f32 && use_quad(d->shape, mi.m, mi.generic != 0, d->B)) ? 1 : 0;
+    ka.stor = f32 ? 1 : 0;
     ka.mf.lo_is_zero = mi.lo_is_zero; ka.mf.phi_ge = mi.phi_ge; ka.mf.obs_clamp = mi.obs_clamp;
     ka.mf.obs_type = mi.obs_fixed ? EPI_OBS_NEWCASES : d->obs_type;
     ka.x_series = in->x_series; ka.u_series = in->u_series;
@@ -1192,6 +1241,9 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     ka.P_MINUS = (om & EPI_OUT_P_MINUS) ? out->P_MINUS : (double *)(ws + wl.p_minus);
     ka.P_PLUS = (om & EPI_OUT_P_PLUS) ? out->P_PLUS : (double *)(ws + wl.p_plus);
     ka.ws_upper = ((om & EPI_OUT_P_MINUS) ? 0 : 1) | ((om & EPI_OUT_P_PLUS) ? 0 : 2);
+    // fp32 storage, 3 states: the packed smoother recomputes s(k+1|k) from s(k|k) (ekf_sym.hpp, RC), nothing reads an
+    // fp64 S_MINUS back -- the forward kernel then stores the caller's fp32 copy only
+    if (f32 && mi.m == 3) ka.S_MINUS = nullptr;
     ka.u_opt = sel(EPI_OUT_U_OPT, out->u_opt);
     ka.u_opt_smooth = has_uos ? sel(EPI_OUT_U_OPT_SMOOTH, out->u_opt_smooth) : nullptr;
     ka.S_SMOOTH = sel(EPI_OUT_S_SMOOTH, out->S_SMOOTH);
@@ -1199,6 +1251,14 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     ka.K_GAIN = sel(EPI_OUT_K_GAIN, out->K_GAIN);
     ka.innovations = sel(EPI_OUT_INNOVATIONS, out->innovations);
     ka.rho = sel(EPI_OUT_RHO, out->rho);
+    ka.f.u_opt = sel32(EPI_OUT_U_OPT, out->u_opt);
+    ka.f.u_opt_smooth = has_uos ? sel32(EPI_OUT_U_OPT_SMOOTH, out->u_opt_smooth) : nullptr;
+    ka.f.S_MINUS = sel32(EPI_OUT_S_MINUS, out->S_MINUS); ka.f.S_PLUS = sel32(EPI_OUT_S_PLUS, out->S_PLUS);
+    ka.f.S_SMOOTH = sel32(EPI_OUT_S_SMOOTH, out->S_SMOOTH);
+    ka.f.P_MINUS = sel32(EPI_OUT_P_MINUS, out->P_MINUS); ka.f.P_PLUS = sel32(EPI_OUT_P_PLUS, out->P_PLUS);
+    ka.f.P_SMOOTH = sel32(EPI_OUT_P_SMOOTH, out->P_SMOOTH);
+    ka.f.K_GAIN = sel32(EPI_OUT_K_GAIN, out->K_GAIN); ka.f.innovations = sel32(EPI_OUT_INNOVATIONS, out->innovations);
+    ka.f.rho = sel32(EPI_OUT_RHO, out->rho);
     ka.pinv_rank = out->pinv_rank; ka.status = out->status;
     ka.X = mi.generic ? (double *)(ws + wl.x) : nullptr;
     ka.rankbuf = mi.generic ? (int32_t *)(ws + wl.rank) : nullptr;
@@ -1212,10 +1272,10 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
             {EPI_OUT_P_SMOOTH, out->P_SMOOTH, "P_SMOOTH"}, {EPI_OUT_K_GAIN, out->K_GAIN, "K_GAIN"},
             {EPI_OUT_INNOVATIONS, out->innovations, "innovations"}, {EPI_OUT_RHO, out->rho, "rho"}};
         for (auto &q : chk)
-            if ((om & q.bit) && !q.p) { char b[128]; snprintf(b, sizeof b, "output %s selected but NULL", q.n); set_err(err, b); return EPI_ERR_BAD_ARG; }
-        if (has_uos && (om & EPI_OUT_U_OPT_SMOOTH) && !out->u_opt_smooth) { set_err(err, "output u_opt_smooth selected but NULL"); return EPI_ERR_BAD_ARG; }
+            if (((om | om32) & q.bit) && !q.p) { char b[128]; snprintf(b, sizeof b, "output %s selected but NULL", q.n); set_err(err, b); return EPI_ERR_BAD_ARG; }
+        if (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH) && !out->u_opt_smooth) { set_err(err, "output u_opt_smooth selected but NULL"); return EPI_ERR_BAD_ARG; }
     }
-    const bool smooth = (om & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && (om & EPI_OUT_U_OPT_SMOOTH)) ||
+    const bool smooth = ((om | om32) & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH)) ||
                         out->pinv_rank || out->status;
     hipStream_t st = (hipStream_t)stream;
     int chunks = d->chunks;
