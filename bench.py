@@ -105,7 +105,11 @@ def pmc_traffic(kernel, args):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_summary.json")))
     if not files:
         return None
-    ks = json.load(open(files[-1]))["kernels"]
+    summ = json.load(open(files[-1]))
+    from epidemicmodeling_amd import _build
+    if summ.get("kernel_src_sha16") != _build.source_hash():
+        return None          # measured on other kernel sources than the ones this run executes: not quoted (stale)
+    ks = summ["kernels"]
     for name, v in ks.items():
         if name.startswith(kernel):
             return v["hbm_bytes"]

@@ -17,6 +17,17 @@ LIB = os.path.join(HERE, "libepiekf.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
+def source_hash() -> str:
+    """sha256 (16 hex digits) of every source the library is built from: stored with profile summaries
+    (profiles/traffic_summary.py) so that bench.py can tell a measurement of THESE kernels from a stale one."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -5,8 +5,12 @@ same 8 B/lane access shape, so  factor_read = 8N / (FETCH_SIZE_calib * 1024)  (t
 16 B/lane streams on gfx950) and likewise for writes; every kernel's raw counter is multiplied by that factor."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from epidemicmodeling_amd import _build  # noqa: E402
 
 CALIB_DOUBLES = 1 << 29
 
@@ -27,7 +31,8 @@ def main(fetch_dir, write_dir, out):
     calib = [k for k in f if "calib_copy" in k][0]
     known = 8.0 * CALIB_DOUBLES
     fr, fw = known / (f[calib] * 1024.0), known / (w[calib] * 1024.0)
-    res = {"calibration": {"bytes_each_way": known, "FETCH_SIZE_KiB": f[calib], "WRITE_SIZE_KiB": w[calib],
+    res = {"kernel_src_sha16": _build.source_hash(),     # bench.py quotes these numbers only for the same kernel sources
+           "calibration": {"bytes_each_way": known, "FETCH_SIZE_KiB": f[calib], "WRITE_SIZE_KiB": w[calib],
                            "read_factor": fr, "write_factor": fw}, "kernels": {}}
     for k in f:
         if "epi::" not in k or "calib" in k or "precheck" in k:
