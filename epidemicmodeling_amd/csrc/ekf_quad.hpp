@@ -20,6 +20,9 @@
 #pragma once
 
 constexpr int kQC = kWave / 4;   // chains per wavefront
+// One wavefront per workgroup.  (Workgroups of four wavefronts -- one per SIMD of a CU -- were measured: every wave ran
+// 30-45 % slower, 1.65 instead of 1.13 ms for the forward kernel at 300 chains; waves that share a CU get in each other's
+// way, so the fewer per CU the better, and single-wave workgroups spread over all CUs first.)
 #ifndef EPI_QUAD_BWD_PF
 #define EPI_QUAD_BWD_PF 0         // smoother: 1 = request a step's inputs one iteration ahead (two register sets); measured
                                   // level with 0 (1.49 vs 1.46 ms, 9 375 chains): the quad kernels are issue-bound, not latency-bound
@@ -175,14 +178,14 @@ EPI_DEV void qload_sym_blk(const double *__restrict__ src, int t, const Lay &l, 
 // A window of L samples is a ring in LDS written TWICE (at pos and pos + L of a 2L-long column): the L samples newest ->
 // oldest are then the contiguous run pos .. pos + L - 1, read with immediate offsets and no wrap arithmetic.
 // LC > 0: L is that compile-time constant (21 is what every caller of the reference passes) and the sum is fully unrolled.
-template <int LC>
+template <int LC, int STRIDE = kQC>
 EPI_DEV double qring_sum(const double *newest_ptr, int L, double newest)
 {
     double sum = newest;
     if (LC) {
         double v[LC > 1 ? LC - 1 : 1];
 #pragma unroll
-        for (int j = 1; j < LC; j++) v[j - 1] = newest_ptr[j * kQC];
+        for (int j = 1; j < LC; j++) v[j - 1] = newest_ptr[j * STRIDE];
 #pragma unroll
         for (int j = 1; j < LC; j++) sum = sum + v[j - 1];
         return sum;
@@ -191,12 +194,68 @@ EPI_DEV double qring_sum(const double *newest_ptr, int L, double newest)
     for (; j + 10 <= L; j += 10) {
         double v[10];
 #pragma unroll
-        for (int q = 0; q < 10; q++) v[q] = newest_ptr[(j + q) * kQC];
+        for (int q = 0; q < 10; q++) v[q] = newest_ptr[(j + q) * STRIDE];
 #pragma unroll
         for (int q = 0; q < 10; q++) sum = sum + v[q];
     }
-    for (; j < L; j++) sum = sum + newest_ptr[j * kQC];
+    for (; j < L; j++) sum = sum + newest_ptr[j * STRIDE];
     return sum;
+}
+
+// ---------------------------------------------------------------------------
+// innovation monitor as a kernel of its own
+// ---------------------------------------------------------------------------
+// GenericEKF.m:172-179.  rho(k) depends on the innovations and on R(k) only.  When R_v is a per-day series (r_mode 1: what
+// TrainPredictPrescribeNPI.m:240 passes) nothing of the monitor feeds back into the filter -- the adaptive R of :180-185
+// needs a scalar R_v -- so the three L-sample window sums (~150 dependent instructions and 2-3 LDS windows per chain and
+// day) leave the sequential forward kernels: they store the innovations, and this kernel, one lane per chain, replays the
+// monitor over them with the very same arithmetic (same window order, same sums).  Used by both lane mappings.
+template <int FLIP, int LC>
+__global__ __launch_bounds__(kWave) void ekf_monitor(const KArgs a, const int *__restrict__ dense_flag)
+{
+    extern __shared__ double lds[];   // two windows [2][2 L][64], double-written (see qring_sum)
+    if (*dense_flag) return;          // the dense kernels keep the monitor inline
+    const int lane = threadIdx.x;
+    const int c = a.c0 + blockIdx.x * kWave + lane;
+    if (c >= a.c0 + a.cn) return;
+    const int T = a.T, L = LC ? LC : a.L;
+    const int sx = a.x_series ? a.x_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    double *winMean = lds + lane, *winCovN = lds + (size_t)2 * L * kWave + lane;
+    for (int j = 0; j < 2 * L; j++) { winMean[j * kWave] = 0.0; winCovN[j * kWave] = 0.0; }
+    int pos = 0;
+    const unsigned voff_x = (unsigned)sx * 8u;
+    // rho(k) is a function of the innovations of steps k-2L+2 .. k only (the normalised window holds L values, each made
+    // from an L-sample mean window), so the time axis is cut into gridDim.y segments: a lane replays the 2L-2 steps before
+    // its segment to refill the two windows (zeros before step 0, exactly as at the start of the filter), then emits
+    const int seg = (T + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int k_lo = (int)blockIdx.y * seg, k_hi = (k_lo + seg < T) ? (k_lo + seg) : T;
+    const int k_begin = (k_lo - (2 * L - 2) > 0) ? (k_lo - (2 * L - 2)) : 0;
+    if (k_lo >= k_hi) return;
+    double in_nxt = a.innovations[lay_scalar(tpos<FLIP>(k_begin, T), lay)];
+    double r_nxt = ldg(a.R_series + (size_t)k_begin * a.Sx, voff_x);
+    for (int k = k_begin; k < k_hi; k++) {
+        const double innov = in_nxt, Rk = r_nxt;
+        if (k + 1 < k_hi) {
+            in_nxt = a.innovations[lay_scalar(tpos<FLIP>(k + 1, T), lay)];
+            r_nxt = ldg(a.R_series + (size_t)(k + 1) * a.Sx, voff_x);     // R_v is not time-flipped (Backward*.m:27)
+        }
+        const int cnt = (k + 1 < L) ? (k + 1) : L;
+        pos = (pos == 0) ? (L - 1) : (pos - 1);
+        double *wm = winMean + pos * kWave;
+        wm[0] = innov; wm[L * kWave] = innov;
+        const double sum = qring_sum<LC, kWave>(wm, L, innov);
+        const double mu = sum / (double)cnt;
+        const double cc = (innov - mu) * (innov - mu);
+        const double ccn = cc / (Rk + kEps);
+        double *wn = winCovN + pos * kWave;
+        wn[0] = ccn; wn[L * kWave] = ccn;
+        const double sumN = qring_sum<LC, kWave>(wn, L, ccn);
+        if (k < k_lo) continue;                                             // still refilling the windows
+        const double rho = sumN / (double)cnt;
+        if (a.rho) a.rho[lay_scalar(k, lay)] = rho;                         // filter-step order also when FLIP
+        if (a.f.rho) a.f.rho[lay_scalar(k, lay)] = (float)rho;
+    }
 }
 
 // rows of the Jacobian a lane multiplies with: its block row's (bi) and its block column's (bj)
@@ -389,11 +448,16 @@ EPI_DEV double qslope(const QNpi &n, const double (&u3)[3], const double (&phi)[
 // ---------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------
-template <int FLIP, int BLK, int LC>
-__global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void ekf_fwd_quad(const KArgs a, const int *__restrict__ dense_flag)
+// MON = 0: the innovation monitor runs as a kernel of its own (ekf_monitor: r_mode 1 only) -- no windows here
+// SOLO = 1: the kernel claims more than half of the register file (a clobbered high accumulation register), so that two of
+// its waves never share a SIMD.  With its ~230 registers the MON = 0 kernel would otherwise be packed two to a SIMD while
+// other SIMDs idle -- measured 1.89 instead of ~1.2 ms at 586 waves.  SOLO = 0 for grids beyond one wave per SIMD.
+template <int FLIP, int BLK, int LC, int MON, int SOLO>
+__global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
-    extern __shared__ double lds[];   // windows [3][2 L][kQC] + gamma*a [12][kQC], one column per chain
+    extern __shared__ double lds[];   // MON: windows [3][2 L][kQC]; then gamma*a [12][kQC], one column per chain
+    if (SOLO) asm volatile("" ::: "a100");
     if (*dense_flag) return;
     Quad Q;
     Q.q = threadIdx.x & 3; Q.lc = threadIdx.x >> 2; Q.bi = (Q.q >> 1) != 0; Q.bj = (Q.q & 1) != 0;
@@ -405,7 +469,7 @@ __global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void ekf_fwd_quad(const KArg
     const Lay lay = make_lay(a, c);
     QPrm p;
     QNpi np;
-    qload_prm(p, np, a, B, c, Q, lds + (size_t)6 * L * kQC + Q.lc);
+    qload_prm(p, np, a, B, c, Q, lds + (size_t)(MON ? 6 * L : 0) * kQC + Q.lc);
     const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
     const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
     const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
@@ -431,7 +495,8 @@ __global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void ekf_fwd_quad(const KArg
 
     // three windows, each a 2L-long column per chain (see qring_sum); `pos` = where the newest sample sits
     double *winMean = lds + Q.lc, *winCov = lds + (size_t)2 * L * kQC + Q.lc, *winCovN = lds + (size_t)4 * L * kQC + Q.lc;
-    for (int j = 0; j < 2 * L; j++) { winMean[j * kQC] = 0.0; winCov[j * kQC] = 0.0; winCovN[j * kQC] = 0.0; }
+    if (MON)
+        for (int j = 0; j < 2 * L; j++) { winMean[j * kQC] = 0.0; winCov[j * kQC] = 0.0; winCovN[j * kQC] = 0.0; }
     int pos = 0;
     const bool fixed_R = (a.r_mode == 0);
     const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
@@ -558,6 +623,7 @@ __global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void ekf_fwd_quad(const KArg
         }
         state_hard_margins<M>(p, sk_minus);
 
+        if (!MON) continue;
         // innovation monitor :172-179 (identical arithmetic to ekf_fwd_sym; the four lanes of a quad hold the same numbers)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
         pos = (pos == 0) ? (L - 1) : (pos - 1);
@@ -591,7 +657,7 @@ __global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void ekf_fwd_quad(const KArg
 // backward recursion (X = pinv(P_MINUS) comes from eks_pinv, packed)
 // ---------------------------------------------------------------------------
 template <int FLIP, int BLK>
-__global__ __launch_bounds__(kWave, EPI_QUAD_WAVES) void eks_bwd_quad(const KArgs a, const int *__restrict__ dense_flag)
+__global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
     __shared__ double galds[kNpi * kQC];   // gamma * a(k), one column per chain

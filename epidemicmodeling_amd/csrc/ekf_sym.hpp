@@ -204,7 +204,8 @@ EPI_DEV void predict_cov_sym(const double (&A)[M * M], const double (&Pp)[M * (M
 //         waves fit a CU AND an eks_pinv wave (168 VGPRs, no LDS) fits beside each of them: the pipelined launch
 //         (epi_batch_desc.chunks = -2) runs one half's eks_pinv grid in the issue slots the other half's forward waves
 //         leave idle.
-template <int M, int FLIP, int LP, int STOR = 0>
+// MON = 0: the innovation monitor runs as a kernel of its own (ekf_monitor, ekf_quad.hpp: r_mode 1 only) -- no windows here
+template <int M, int FLIP, int LP, int STOR = 0, int MON = 1>
 __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
     extern __shared__ double lds[];   // three sliding windows [3][L][stride], one column per lane (+ [48][stride], LP)
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
 
     constexpr int stride = LP ? kPipeLanes : kWave;   // compile-time: LDS offsets stay immediates
     typename PrmSelect<LP>::type p;
-    init_prm<M>(p, a, B, c, lds + (size_t)3 * L * stride + lane, stride);
+    init_prm<M>(p, a, B, c, lds + (size_t)(MON ? 3 * L : 0) * stride + lane, stride);
     const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
     const double beta = a.prm[(size_t)EPI_PRM_BETA_EKF * B + c];
     const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
@@ -237,7 +238,8 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         for (int i = 0; i <= j; i++) Pm[sidx(i, j)] = a.Ps_init[(size_t)IXM(i, j) * B + c];
 
     double *winMean = lds + lane, *winCov = lds + (size_t)L * stride + lane, *winCovN = lds + (size_t)2 * L * stride + lane;
-    for (int j = 0; j < L; j++) { winMean[j * stride] = 0.0; winCov[j * stride] = 0.0; winCovN[j * stride] = 0.0; }
+    if (MON)
+        for (int j = 0; j < L; j++) { winMean[j * stride] = 0.0; winCov[j * stride] = 0.0; winCovN[j * stride] = 0.0; }
     int head = 0;
     const bool fixed_R = (a.r_mode == 0);
     const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
@@ -360,6 +362,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
             store_rows_f32<M>(a.f.K_GAIN, t, M, lay, K); store_scalar_f32(a.f.innovations, t, lay, innov);
         }
 
+        if (!MON) continue;
         // innovation monitor (identical to ekf_fwd)
         const int cnt = (k + 1 < L) ? (k + 1) : L;
         head = (head == 0) ? (L - 1) : (head - 1);

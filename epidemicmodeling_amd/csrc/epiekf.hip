@@ -64,6 +64,7 @@ struct KArgs {
     // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
     // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
     int stor;   // 1: fp32 storage (see F32 below)
+    int mon_hoist;   // 1: the packed / quad forward kernels skip the innovation monitor, ekf_monitor replays it (r_mode 1)
     struct F32 { float *u_opt, *u_opt_smooth, *S_MINUS, *S_PLUS, *S_SMOOTH, *P_MINUS, *P_PLUS, *P_SMOOTH, *K_GAIN, *innovations, *rho; } f;
 };
 
@@ -790,12 +791,19 @@ static int hip_fail(char *err, hipError_t e, const char *what)
     return EPI_ERR_HIP;
 }
 
-struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, total; };
+struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, innov, total; };
 static int lane_block_of(const epi_batch_desc *d) { return (d->lane_block <= 0 || d->lane_block >= d->B) ? d->B : d->lane_block; }
 static size_t padded_chains(const epi_batch_desc *d)
 {
     const int blk = lane_block_of(d);
     return (size_t)((d->B + blk - 1) / blk) * blk;
+}
+// The innovation monitor leaves the forward kernels (ekf_monitor, ekf_quad.hpp) when R_v is a per-day series -- then rho
+// feeds nothing back -- and two double-written L-sample windows per lane fit the default dynamic-LDS limit.
+static bool monitor_hoisted(const epi_batch_desc *d)
+{
+    return MODEL_TABLE[d->model].generic && d->r_mode == 1 && d->q_mode == 0 && d->path_hint != 2 &&
+           (size_t)4 * d->L * kWave * sizeof(double) <= 64u * 1024u && !getenv("EPIEKF_MON_INLINE");
 }
 static WsLayout ws_layout(const epi_batch_desc *d)
 {
@@ -816,6 +824,8 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.x = take(generic, (size_t)d->T * (m * (m + 1) / 2) * Bp * sizeof(double));   // packed upper triangle of X
     w.rank = take(generic, (size_t)d->T * Bp * sizeof(int32_t));
     w.flag = take(generic, 256);
+    // ekf_monitor reads the fp64 innovations: workspace when the caller does not take them as an fp64 output
+    w.innov = take(monitor_hoisted(d) && (d->storage || !(d->out_mask & EPI_OUT_INNOVATIONS)), (size_t)d->T * Bp * sizeof(double));
     w.total = off;
     return w;
 }
@@ -926,6 +936,23 @@ static bool use_quad(int shape, int m, bool generic, int B)
     return ((long)B + kQC - 1) / kQC <= (long)simd_count();   // the quad waves still get a SIMD each (one round)
 }
 
+// the innovation monitor of a chain range as its own launch (after the forward kernel that wrote the innovations)
+template <int FLIP>
+static hipError_t launch_monitor(const KArgs &ka, int cn, hipStream_t st)
+{
+    if (!ka.mon_hoist || !(ka.rho || ka.f.rho)) return hipSuccess;
+    const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
+    const int mb = (cn + kWave - 1) / kWave;
+    // time segments (each pays a 2L-2-step warm-up): enough of them that the grid gives every SIMD about two waves, none
+    // shorter than ~64 steps
+    int nseg = (2 * simd_count() + mb - 1) / mb;
+    const int max_seg = ka.T / 64 > 1 ? ka.T / 64 : 1;
+    nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
+    if (ka.L == 21) hipLaunchKernelGGL((ekf_monitor<FLIP, 21>), dim3(mb, nseg), dim3(kWave), shm, st, ka, ka.dense_flag);
+    else hipLaunchKernelGGL((ekf_monitor<FLIP, 0>), dim3(mb, nseg), dim3(kWave), shm, st, ka, ka.dense_flag);
+    return hipGetLastError();
+}
+
 // phase: 0 = everything; 1 = forward kernel; 2 = smoother (pinv + backward); 3 = pinv kernel; 4 = backward kernel
 template <int M, int FLIP, int GENERIC>
 static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth, int hint, size_t shmem, hipStream_t st)
@@ -941,12 +968,21 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
             const int qblocks = (cn + kQC - 1) / kQC;
             if (phase == 0 || phase == 1) {
                 // the specialisation for the layout and the window length this shape is meant for, or the general one
-                const size_t qshm = ((size_t)6 * ka.L + kNpi) * kQC * sizeof(double);
-                if (ka.blk == kQC && ka.L == 21)
-                    hipLaunchKernelGGL((ekf_fwd_quad<FLIP, kQC, 21>), dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
-                else
-                    hipLaunchKernelGGL((ekf_fwd_quad<FLIP, 0, 0>), dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
+                const size_t qshm = ((size_t)(ka.mon_hoist ? 0 : 6 * ka.L) + kNpi) * kQC * sizeof(double);
+                const bool fast = ka.blk == kQC && ka.L == 21;
+                const bool solo = qblocks <= simd_count();       // every wave can have a SIMD of its own: keep it that way
+                auto go = [&](auto kern) -> hipError_t {
+                    hipLaunchKernelGGL(kern, dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
+                    return hipGetLastError();
+                };
+                if (ka.mon_hoist) {
+                    if (solo) e = fast ? go(ekf_fwd_quad<FLIP, kQC, 21, 0, 1>) : go(ekf_fwd_quad<FLIP, 0, 0, 0, 1>);
+                    else e = fast ? go(ekf_fwd_quad<FLIP, kQC, 21, 0, 0>) : go(ekf_fwd_quad<FLIP, 0, 0, 0, 0>);
+                } else {
+                    e = fast ? go(ekf_fwd_quad<FLIP, kQC, 21, 1, 0>) : go(ekf_fwd_quad<FLIP, 0, 0, 1, 0>);
+                }
+                if (e != hipSuccess) return e;
+                if ((e = launch_monitor<FLIP>(ka, cn, st)) != hipSuccess) return e;
                 if (run_dense) {
                     hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
                     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -975,10 +1011,16 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
             // instead of 408 VGPRs (a third of the AGPR traffic), still four workgroups per CU
             const size_t per_lane = ((size_t)3 * ka.L + 4 * kNpi) * sizeof(double);
             const bool lp = M == 6 && ka.lw <= kPipeLanes && per_lane * kPipeLanes * 4 <= 160u * 1024u && !getenv("EPIEKF_NO_LP");
-            if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
+            if (ka.mon_hoist) {         // no windows in LDS: only the LP variant's model vectors
+                const size_t lp_shm = (size_t)4 * kNpi * kPipeLanes * sizeof(double);
+                if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1, 0>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1, 0, 0>), dim3(blocks), dim3(kWave), lp_shm, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 0, 0>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+            } else if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
             else if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), per_lane * kPipeLanes, st, ka, ka.dense_flag);
             else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
             if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = launch_monitor<FLIP>(ka, cn, st)) != hipSuccess) return e;
         }
         if (run_dense) {
             hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
@@ -1260,6 +1302,8 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     ka.f.K_GAIN = sel32(EPI_OUT_K_GAIN, out->K_GAIN); ka.f.innovations = sel32(EPI_OUT_INNOVATIONS, out->innovations);
     ka.f.rho = sel32(EPI_OUT_RHO, out->rho);
     ka.pinv_rank = out->pinv_rank; ka.status = out->status;
+    ka.mon_hoist = monitor_hoisted(d) ? 1 : 0;
+    if (ka.mon_hoist && !ka.innovations && (ka.rho || ka.f.rho)) ka.innovations = (double *)(ws + wl.innov);
     ka.X = mi.generic ? (double *)(ws + wl.x) : nullptr;
     ka.rankbuf = mi.generic ? (int32_t *)(ws + wl.rank) : nullptr;
     ka.pinv_pos0 = mi.flipped ? 0 : 1;
