@@ -285,7 +285,10 @@ def main():
     # (the chunked modes overlap the stages of different chunks inside ONE call, so there the timed passes use that one
     # call and the per-kernel durations come from K further passes enqueued stage by stage)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    staged = args.chunks in (0, 1)
+    # The timed passes are the call a user makes (one epi_ekf_run_device per pass): inside it the library may overlap the
+    # stages (the pipelined-in-time launch of a batch that leaves SIMDs idle).  The per-kernel durations come from K further
+    # passes enqueued stage by stage.  EPI_BENCH_STAGED=1: time the staged passes instead (round-1 behaviour).
+    staged = os.environ.get("EPI_BENCH_STAGED") == "1"
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(evs[k] if staged else None)

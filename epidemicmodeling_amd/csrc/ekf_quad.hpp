@@ -493,6 +493,13 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
             Pm[r][cc] = a.Ps_init[(size_t)(i < j ? IXM(i, j) : IXM(j, i)) * B + c];
         }
 
+    // time segments: see ekf_fwd_sym
+    const int k_begin = a.k_begin, k_end = (a.k_end > 0 && a.k_end < T) ? a.k_end : T;
+    if (k_begin > 0) {
+        qload_vec<BLK>(a.S_MINUS, tpos<FLIP>(k_begin, T), lay, sk_minus);
+        const QOff o36 = qoffsets<BLK>(Q, lay, true);
+        qload_sym_blk(a.P_MINUS, tpos<FLIP>(k_begin, T), lay, o36, 36, Pm);
+    }
     // three windows, each a 2L-long column per chain (see qring_sum); `pos` = where the newest sample sits
     double *winMean = lds + Q.lc, *winCov = lds + (size_t)2 * L * kQC + Q.lc, *winCovN = lds + (size_t)4 * L * kQC + Q.lc;
     if (MON)
@@ -503,12 +510,12 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
     double R_next = R_v;
 
     const unsigned voff_x = (unsigned)sx * 8u;
-    double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(0, T) * a.Sx, voff_x);
-    double r_nxt = fixed_R ? 0.0 : ldg(a.R_series, voff_x);
+    double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(k_begin, T) * a.Sx, voff_x);
+    double r_nxt = fixed_R ? 0.0 : ldg(a.R_series + (size_t)k_begin * a.Sx, voff_x);
     double u_nxt[3];
-    qload_u(a, tpos<FLIP>(0, T), su, Q, u_nxt);
+    qload_u(a, tpos<FLIP>(k_begin, T), su, Q, u_nxt);
 
-    for (int k = 0; k < T; k++) {
+    for (int k = k_begin; k < k_end; k++) {
         const int t = tpos<FLIP>(k, T);
         const double Rk = fixed_R ? R_next : r_nxt;
         const double xk = x_nxt;
@@ -650,6 +657,10 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
                 R_next = R_v;
             }
         }
+    }
+    if (k_end < T) {       // hand-over to the next time segment
+        qstore_vec<BLK>(a.S_MINUS, tpos<FLIP>(k_end, T), lay, Q, sk_minus);
+        qstore_blk<BLK>(a.P_MINUS, tpos<FLIP>(k_end, T), lay, Q, Pm);
     }
 }
 

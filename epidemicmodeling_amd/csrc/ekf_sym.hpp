@@ -236,6 +236,14 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     for (int j = 0; j < M; j++)
 #pragma unroll
         for (int i = 0; i <= j; i++) Pm[sidx(i, j)] = a.Ps_init[(size_t)IXM(i, j) * B + c];
+    // Time segments (launch_chain, "pipelined in time"): this launch runs filter steps [k_begin, k_end).  A later segment
+    // resumes from s(k|k-1), P(k|k-1) exactly as the previous one left them in S_MINUS / P_MINUS (fp64, stored below when
+    // the segment ends before T) -- the same values the single launch would carry in registers.  MON = 0 only (no windows).
+    const int k_begin = a.k_begin, k_end = (a.k_end > 0 && a.k_end < T) ? a.k_end : T;
+    if (k_begin > 0) {
+        load_vec<M>(a.S_MINUS, tpos<FLIP>(k_begin, T), lay, sk_minus);
+        load_sym<M>(a.P_MINUS, tpos<FLIP>(k_begin, T), lay, Pm);
+    }
 
     double *winMean = lds + lane, *winCov = lds + (size_t)L * stride + lane, *winCovN = lds + (size_t)2 * L * stride + lane;
     if (MON)
@@ -249,12 +257,12 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     // load issued after a step's ~100 stores would wait for all of them to drain; the inputs of step k+1 are
     // therefore requested at the top of step k, ahead of its stores, and consumed one iteration later.
     const unsigned voff = (unsigned)c * 8u, voff_x = (unsigned)sx * 8u;
-    double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(0, T) * a.Sx, voff_x);
-    double r_nxt = fixed_R ? 0.0 : ldg(a.R_series, voff_x);
+    double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(k_begin, T) * a.Sx, voff_x);
+    double r_nxt = fixed_R ? 0.0 : ldg(a.R_series + (size_t)k_begin * a.Sx, voff_x);
     double u_nxt[kNpi];
-    load_u(a, tpos<FLIP>(0, T), su, u_nxt);
+    load_u(a, tpos<FLIP>(k_begin, T), su, u_nxt);
 
-    for (int k = 0; k < T; k++) {
+    for (int k = k_begin; k < k_end; k++) {
         const int t = tpos<FLIP>(k, T);
         const double Rk = fixed_R ? R_next : r_nxt;
         const double xk = x_nxt;
@@ -386,6 +394,10 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
                 R_next = R_v;
             }
         }
+    }
+    if (k_end < T) {       // hand-over to the next time segment
+        store_vec<M>(a.S_MINUS, tpos<FLIP>(k_end, T), lay, sk_minus);
+        store_sym<M>(a.P_MINUS, tpos<FLIP>(k_end, T), lay, Pm, (a.ws_upper & 1) != 0);
     }
 }
 

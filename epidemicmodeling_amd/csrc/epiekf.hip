@@ -64,6 +64,8 @@ struct KArgs {
     // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
     // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
     int stor;   // 1: fp32 storage (see F32 below)
+    int k_begin, k_end;   // filter steps [k_begin, k_end) of this forward launch (k_end <= 0: up to T); eks_pinv: steps from pinv_step0
+    int pinv_step0;
     int mon_hoist;   // 1: the packed / quad forward kernels skip the innovation monitor, ekf_monitor replays it (r_mode 1)
     struct F32 { float *u_opt, *u_opt_smooth, *S_MINUS, *S_PLUS, *S_SMOOTH, *P_MINUS, *P_PLUS, *P_SMOOTH, *K_GAIN, *innovations, *rho; } f;
 };
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     if (cl >= a.cn) return;
     const int B = a.B;
     // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
-    const int t1 = a.pinv_pos0 + (int)blockIdx.y;
+    const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)blockIdx.y;
     const int c = a.c0 + cl;
     const Lay lay = make_lay(a, c);
     double P[M * M];
@@ -849,7 +851,7 @@ struct SideStreams {
 static thread_local SideStreams g_side;   // helper streams of the calling thread (created on first use)
 
 // a helper stream of the LOWEST priority: its eks_pinv workgroups are placed after the forward kernel's (pipelined launch)
-struct LowPrioStream { hipStream_t stream = nullptr; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; int device = -1; };
+struct LowPrioStream { hipStream_t stream = nullptr; hipEvent_t ev[10] = {}; int device = -1; };
 static thread_local LowPrioStream g_low;
 static hipError_t low_prio_stream(LowPrioStream **out)
 {
@@ -941,6 +943,7 @@ template <int FLIP>
 static hipError_t launch_monitor(const KArgs &ka, int cn, hipStream_t st)
 {
     if (!ka.mon_hoist || !(ka.rho || ka.f.rho)) return hipSuccess;
+    if (ka.k_end > 0 && ka.k_end < ka.T) return hipSuccess;      // a time segment that is not the last: innovations incomplete
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
     const int mb = (cn + kWave - 1) / kWave;
     // time segments (each pays a 2L-2-step warm-up): enough of them that the grid gives every SIMD about two waves, none
@@ -1100,6 +1103,45 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
         }
         return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
     }
+    if (GENERIC && phase == 0 && (chunks == 0 || chunks == 1 || chunks == -3) && smooth && hint == 1 && ka.mon_hoist && !ka.stor &&
+        ka.T >= 128 && !getenv("EPIEKF_NO_TIME_PIPE")) {
+        // Pipelined in TIME.  A batch that does not fill the chip (the shards of the sweep on 2, 4, 8 GPUs) leaves SIMDs idle
+        // while its sequential forward waves crawl through the T days, and pinv(P(k|k-1)) needs nothing but the forward
+        // pass's output of day k: the forward kernel runs in kTimeSeg launches of T / kTimeSeg days each (a later segment
+        // resumes from the S_MINUS / P_MINUS the previous one stored: same bits), and after each of them the eks_pinv grid
+        // of ITS days starts on a second stream, beside the next forward segment.  Only the last segment's pinv is left
+        // when the forward pass ends.  Not for a batch that fills the chip (nothing idles: measured level, round 1).
+        const bool quad = ka.quad != 0;
+        const long fwd_waves = quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
+        if (chunks == -3 || fwd_waves * 4 <= (long)simd_count() * 3) {
+            constexpr int kTimeSeg = 4;
+            LowPrioStream *lp = nullptr;
+            if ((e = low_prio_stream(&lp)) != hipSuccess) return e;
+            const int T = ka.T;
+            for (int sg = 0; sg < kTimeSeg; sg++) {
+                KArgs kc = ka;
+                kc.k_begin = (int)((long)T * sg / kTimeSeg);
+                kc.k_end = (sg == kTimeSeg - 1) ? T : (int)((long)T * (sg + 1) / kTimeSeg);
+                if ((e = enqueue_chunk<M, FLIP, GENERIC>(kc, 0, ka.B, 1, smooth, hint, shmem, st)) != hipSuccess) return e;
+                if ((e = hipEventRecord(lp->ev[sg], st)) != hipSuccess) return e;
+                if ((e = hipStreamWaitEvent(lp->stream, lp->ev[sg], 0)) != hipSuccess) return e;
+                // filter steps whose P(j|j-1) exists now and has not been inverted yet: j_lo .. j_hi (the smoother needs
+                // j = 1 .. T-1); array position of step j: j, or T-1-j for the time-flipped models
+                const int j_lo = kc.k_begin + 1, j_hi = (kc.k_end < T) ? kc.k_end : T - 1;
+                if (j_hi >= j_lo) {
+                    KArgs kp = ka;
+                    kp.c0 = 0; kp.cn = ka.B;
+                    kp.pinv_step0 = FLIP ? (T - 1 - j_hi) : (j_lo - 1);
+                    hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(j_hi - j_lo + 1)),
+                                       dim3(pinv_wg<M>()), 0, lp->stream, kp);
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                }
+            }
+            if ((e = hipEventRecord(lp->ev[kTimeSeg], lp->stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(st, lp->ev[kTimeSeg], 0)) != hipSuccess) return e;
+            return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, 4, smooth, hint, shmem, st);
+        }
+    }
     if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1 && !ka.quad && !ka.stor) {
         // Pipelined halves.  The forward kernel of the second half and the eks_pinv grid of the first half are in flight
         // together, and -- because this forward variant (LDS-resident model constants, LDS sized by the lanes used)
@@ -1207,7 +1249,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     // three fp64 windows of L samples per lane must fit the CU's 160 KiB LDS
     if (d->phase < 0 || d->phase > 4) { set_err(err, "phase must be 0..4"); return EPI_ERR_BAD_ARG; }
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
-    if (d->chunks < -2) { set_err(err, "chunks must be >= -2"); return EPI_ERR_BAD_ARG; }
+    if (d->chunks < -3) { set_err(err, "chunks must be >= -3"); return EPI_ERR_BAD_ARG; }
     if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
     if (d->shape < 0 || d->shape > 2) { set_err(err, "shape must be 0 (auto), 1 (lane per chain) or 2 (quad per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }

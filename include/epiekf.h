@@ -125,7 +125,11 @@ typedef struct epi_batch_desc {
                              kernels leave idle; 0/1: one chunk on the caller's stream; -1: "rounds + tail" (the
                              waves beyond a whole number of one-wave-per-SIMD rounds form the second chunk);
                              -2: "pipelined halves" (generic models, path_hint = 1): the second half's forward
-                             kernel and the first half's eks_pinv grid share the SIMDs */
+                             kernel and the first half's eks_pinv grid share the SIMDs;
+                             -3: force "pipelined in time" (forward kernel in four time segments, each followed by the
+                             eks_pinv grid of its days on a second stream) -- what 0 / 1 choose by themselves for a full
+                             call of a batch that leaves a quarter of the SIMDs idle (generic models, path_hint = 1,
+                             R_v a per-day series, T >= 128) */
     int32_t lane_block;   /* layout of the OUTPUT arrays (and of the workspace) of epi_ekf_run_device.  0 or >= B: the
                              classic [T][rows][B].  blk in 1..B-1 (8 recommended): chain-blocked,
                              element (t, row, c) at ((t*nblk + c/blk)*rows + row)*blk + c%blk, nblk = ceil(B/blk) --
