@@ -66,6 +66,7 @@ struct KArgs {
     int stor;   // 1: fp32 storage (see F32 below)
     int k_begin, k_end;   // filter steps [k_begin, k_end) of this forward launch (k_end <= 0: up to T); eks_pinv: steps from pinv_step0
     int pinv_step0;
+    int mon_defer;   // 1: this launch does not enqueue ekf_monitor itself (the caller does, later)
     int mon_hoist;   // 1: the packed / quad forward kernels skip the innovation monitor, ekf_monitor replays it (r_mode 1)
     struct F32 { float *u_opt, *u_opt_smooth, *S_MINUS, *S_PLUS, *S_SMOOTH, *P_MINUS, *P_PLUS, *P_SMOOTH, *K_GAIN, *innovations, *rho; } f;
 };
@@ -943,7 +944,7 @@ template <int FLIP>
 static hipError_t launch_monitor(const KArgs &ka, int cn, hipStream_t st)
 {
     if (!ka.mon_hoist || !(ka.rho || ka.f.rho)) return hipSuccess;
-    if (ka.k_end > 0 && ka.k_end < ka.T) return hipSuccess;      // a time segment that is not the last: innovations incomplete
+    if (ka.mon_defer) return hipSuccess;
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
     const int mb = (cn + kWave - 1) / kWave;
     // time segments (each pays a 2L-2-step warm-up): enough of them that the grid gives every SIMD about two waves, none
@@ -1122,6 +1123,8 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
                 KArgs kc = ka;
                 kc.k_begin = (int)((long)T * sg / kTimeSeg);
                 kc.k_end = (sg == kTimeSeg - 1) ? T : (int)((long)T * (sg + 1) / kTimeSeg);
+                // (the monitor kernel follows after the loop, beside the last segment's pinv grid, not in front of it)
+                kc.mon_defer = 1;
                 if ((e = enqueue_chunk<M, FLIP, GENERIC>(kc, 0, ka.B, 1, smooth, hint, shmem, st)) != hipSuccess) return e;
                 if ((e = hipEventRecord(lp->ev[sg], st)) != hipSuccess) return e;
                 if ((e = hipStreamWaitEvent(lp->stream, lp->ev[sg], 0)) != hipSuccess) return e;
@@ -1137,6 +1140,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
                     if ((e = hipGetLastError()) != hipSuccess) return e;
                 }
             }
+            { KArgs km = ka; km.c0 = 0; km.cn = ka.B; if ((e = launch_monitor<FLIP>(km, ka.B, st)) != hipSuccess) return e; }
             if ((e = hipEventRecord(lp->ev[kTimeSeg], lp->stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(st, lp->ev[kTimeSeg], 0)) != hipSuccess) return e;
             return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, 4, smooth, hint, shmem, st);
