@@ -947,9 +947,10 @@ static hipError_t launch_monitor(const KArgs &ka, int cn, hipStream_t st)
     if (ka.mon_defer) return hipSuccess;
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
     const int mb = (cn + kWave - 1) / kWave;
-    // time segments (each pays a 2L-2-step warm-up): enough of them that the grid gives every SIMD about two waves, none
-    // shorter than ~64 steps
-    int nseg = (2 * simd_count() + mb - 1) / mb;
+    // time segments (each pays a 2L-2-step warm-up): enough of them that the grid gives every SIMD about eight of these
+    // light waves (a lane's 100-step scan is latency-bound: 0.70 ms with two segments, 0.25 ms with eight at 75 000 chains),
+    // none shorter than ~64 steps
+    int nseg = (8 * simd_count() + mb - 1) / mb;
     const int max_seg = ka.T / 64 > 1 ? ka.T / 64 : 1;
     nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
     if (ka.L == 21) hipLaunchKernelGGL((ekf_monitor<FLIP, 21>), dim3(mb, nseg), dim3(kWave), shm, st, ka, ka.dense_flag);
@@ -1180,6 +1181,21 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
             if ((e = hipStreamWaitEvent(st, lp->ev[2], 0)) != hipSuccess) return e;
             return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, 4, smooth, hint, shmem, st);
         }
+    }
+    if (GENERIC && phase == 0 && chunks <= 1 && smooth && hint == 1 && ka.mon_hoist && (ka.rho || ka.f.rho)) {
+        // a full call on one stream: the monitor kernel needs the forward pass only, so it runs on the helper stream beside the
+        // pinv grid and the smoother instead of in front of them
+        LowPrioStream *lp = nullptr;
+        if ((e = low_prio_stream(&lp)) != hipSuccess) return e;
+        KArgs kc = ka;
+        kc.mon_defer = 1;
+        if ((e = enqueue_chunk<M, FLIP, GENERIC>(kc, 0, ka.B, 1, smooth, hint, shmem, st)) != hipSuccess) return e;
+        if ((e = hipEventRecord(lp->ev[0], st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(lp->stream, lp->ev[0], 0)) != hipSuccess) return e;
+        { KArgs km = ka; km.c0 = 0; km.cn = ka.B; if ((e = launch_monitor<FLIP>(km, ka.B, lp->stream)) != hipSuccess) return e; }
+        if ((e = hipEventRecord(lp->ev[1], lp->stream)) != hipSuccess) return e;
+        if ((e = enqueue_chunk<M, FLIP, GENERIC>(kc, 0, ka.B, 2, smooth, hint, shmem, st)) != hipSuccess) return e;
+        return hipStreamWaitEvent(st, lp->ev[1], 0);
     }
     if (phase != 0 || chunks <= 1 || ka.B < chunks * kWave)
         return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);

@@ -29,8 +29,9 @@ for _ in range(2):
                                                     C.c_void_p(st.cuda_stream), err), err)
 torch.cuda.synchronize()
 del src, dst
-w = synth.make_cfg4()
-r = batch.EkfRunner(batch.DeviceWorkload(w, dev), lane_block="auto")   # bench.py's default layout
+# `python traffic_probe.py shard`: the 9 375-chain shard one of 8 GPUs runs (four lanes per chain) instead of the whole sweep
+w = synth.make_cfg4(75, 125) if (len(sys.argv) > 1 and sys.argv[1] == "shard") else synth.make_cfg4()
+r = batch.EkfRunner(batch.DeviceWorkload(w, dev), lane_block="auto")   # bench.py's default layout and lane mapping
 for _ in range(2):
     for ph in (1, 3, 4):
         r.run(phase=ph)

@@ -1,0 +1,17 @@
+# Collects the round-2 profiles on the GPU box (run through gpurun); results land in gpurun_out/r02/.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
+SQ="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats75k -o bench -- python3 $R/bench.py --no-cpu-baseline > $O/bench_cfg4_under_rocprof.json 2>/dev/null && echo stats75k
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats9375 -o bench -- python3 $R/bench.py --no-cpu-baseline --regions 75 --eps 125 > $O/bench_shard9375_under_rocprof.json 2>/dev/null && echo stats9375
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $R/profiles/traffic_probe.py > /dev/null 2>&1 && echo fetch
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $R/profiles/traffic_probe.py > /dev/null 2>&1 && echo write
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/pmc_sq -o p -- python3 $R/profiles/traffic_probe.py > /dev/null 2>&1 && echo sq75k
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/pmc_sq_shard -o p -- python3 $R/profiles/traffic_probe.py shard > /dev/null 2>&1 && echo sqshard
+cd $R
+f() { find $1 -name "p_counter_collection.csv" | head -1 | xargs dirname; }
+python3 profiles/traffic_summary.py $(f $O/pmc_fetch) $(f $O/pmc_write) $O/traffic_summary.json > /dev/null && echo traffic ok
+python3 profiles/valu_summary.py $(f $O/pmc_sq) $O/valu_summary.json > /dev/null && echo valu ok
+python3 profiles/valu_summary.py $(f $O/pmc_sq_shard) $O/valu_summary_shard9375.json > /dev/null && echo valu shard ok
+find $O -name "*kernel_stats.csv" -exec sh -c 'cp "$1" $2/$(basename $(dirname $(dirname "$1")))_kernel_stats.csv' _ {} $O \; 2>/dev/null
+ls $O
