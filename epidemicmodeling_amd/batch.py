@@ -197,7 +197,16 @@ def gather_shards_to_root(t: torch.Tensor, B_total: int, group=None, dst: int = 
     per = (B_total + world - 1) // world
     if t.shape[-1] < per:
         t = torch.nn.functional.pad(t, (0, per - t.shape[-1]))
-    parts = gather_to_root(t.contiguous(), group=group, dst=dst)
+    t = t.contiguous()
+    if world > 1 and dist.get_backend(group) == "nccl":
+        # RCCL: one ncclAllGather of the small per-chain summaries (16 B per chain) -- every rank receives
+        # them, rank `dst` uses them
+        buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf, t, group=group)
+        if dist.get_rank(group) != dst:
+            return None
+        return torch.cat(list(buf.unbind(0)), dim=-1)[..., :B_total]
+    parts = gather_to_root(t, group=group, dst=dst)
     if dist.get_rank(group) != dst:
         return None
     return torch.cat([p_.to(t.device) for p_ in parts], dim=-1)[..., :B_total]
