@@ -77,8 +77,8 @@ class EkfRunner:
         self.mask = out_mask_of(names)
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
                                    dw.r_mode, self.mask, dw.q_mode)
-        # epi_batch_desc.shape: 0 = by batch size, 1 = one lane per chain, 2 = four lanes per chain (6-state generic models)
-        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2}.get(shape, shape)
+        # epi_batch_desc.shape: 0 = by batch size, 1 / 2 / 3 = one / four / two lanes per chain (6-state generic models)
+        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2, "pair": 3}.get(shape, shape)
         # epi_batch_desc.storage: "f32" = outputs stored as float32 (each the fp64 result rounded once; BASELINE config 5)
         self.desc.storage = {"f64": 0, "f32": 1}[storage]
         odt = torch.float32 if storage == "f32" else torch.float64

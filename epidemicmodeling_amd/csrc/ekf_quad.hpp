@@ -457,7 +457,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_quad(const KArgs a, const int *
 {
     constexpr int M = 6;
     extern __shared__ double lds[];   // MON: windows [3][2 L][kQC]; then gamma*a [12][kQC], one column per chain
-    if (SOLO) asm volatile("" ::: "a100");
+    if (SOLO) asm volatile("" ::: "a130");     // 228 + 131 registers: not even an eks_pinv wave (168) fits beside it
     if (*dense_flag) return;
     Quad Q;
     Q.q = threadIdx.x & 3; Q.lc = threadIdx.x >> 2; Q.bi = (Q.q >> 1) != 0; Q.bj = (Q.q & 1) != 0;

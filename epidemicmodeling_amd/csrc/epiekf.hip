@@ -60,6 +60,8 @@ struct KArgs {
     // bound by HBM / per-CU memory throughput, which scales with active lanes, not by wave count.
     int lw;
     int quad;   // 6-state generic models: four lanes per chain (ekf_quad.hpp) instead of one
+    int pair;   // ... two lanes per chain (ekf_pair.hpp)
+    int x_full; // eks_pinv stores X with all 36 rows (the pair smoother reads whole rows) instead of the packed upper triangle
     // epi_batch_desc.storage = 1: the caller's outputs are fp32 arrays (same layouts, 4-byte elements); each selected
     // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
     // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
@@ -455,7 +457,12 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     constexpr int BZS = (M >= 6) ? pinv_wg<M>() : 0;
     __shared__ double bzs[BZS ? 2 * M * BZS : 1];
     const int rank = sym_pinv<M, BZS>(P, X, &capped, bzs + threadIdx.x);           // :215
-    {   // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
+    if (a.x_full) {
+        unsigned voff, rowb;
+        const rsrc_t r = lay_slice(a.X, t1, M * M, lay, voff, rowb);
+#pragma unroll
+        for (int e = 0; e < M * M; e++) bst(r, voff, (unsigned)e * rowb, X[e]);
+    } else {   // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
         constexpr int NSX = M * (M + 1) / 2;
         unsigned voff, rowb;
         const rsrc_t r = lay_slice(a.X, t1, NSX, lay, voff, rowb);
@@ -614,6 +621,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 
 #include "ekf_sym.hpp"
 #include "ekf_quad.hpp"
+#include "ekf_pair.hpp"
 
 // ---------------------------------------------------------------------------
 // forward simulators
@@ -808,6 +816,46 @@ static bool monitor_hoisted(const epi_batch_desc *d)
     return MODEL_TABLE[d->model].generic && d->r_mode == 1 && d->q_mode == 0 && d->path_hint != 2 &&
            (size_t)4 * d->L * kWave * sizeof(double) <= 64u * 1024u && !getenv("EPIEKF_MON_INLINE");
 }
+// Which lane mapping runs the 6-state generic models (epi_batch_desc.shape).  Auto: four lanes per chain while every
+// quad wavefront (16 chains) still gets a SIMD of its own, i.e. up to 16 384 chains on MI355X -- there the chains'
+// per-day latency is what counts and the quad kernels' instruction stream is half as long (9 375 chains: 3.9 instead of
+// 6.1 ms per pass); beyond that the quad waves (one per SIMD at ~290 registers) would run in rounds and one lane per
+// chain, the shape with the least total work, wins (18 750 chains: 7.1 against 9.0 ms).  profiles/r02/batch_size_sweep.txt.
+// EPIEKF_SHAPE=1|2 overrides (measurement).
+static int g_simd_count = 0;
+static int simd_count()
+{
+    if (!g_simd_count) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        g_simd_count = cus * 4;
+    }
+    return g_simd_count;
+}
+// returns EPI_SHAPE_LANE, _QUAD or _PAIR.  pair_ok: the pair kernels have no inline monitor (R_v must be a per-day series)
+static int pick_shape(int shape, int m, bool generic, int B, bool pair_ok)
+{
+    if (m != 6 || !generic) return EPI_SHAPE_LANE;
+    if (const char *env = getenv("EPIEKF_SHAPE")) { const int v = atoi(env); if (v >= 1 && v <= 3) shape = v; }
+    if (shape == EPI_SHAPE_PAIR) return pair_ok ? EPI_SHAPE_PAIR : EPI_SHAPE_LANE;
+    if (shape == EPI_SHAPE_QUAD || shape == EPI_SHAPE_LANE) return shape;
+    if (((long)B + kQC - 1) / kQC <= (long)simd_count()) return EPI_SHAPE_QUAD;   // the quad waves still get a SIMD each
+    // (two lanes per chain is never chosen here: measured between the other two everywhere -- 18 750 chains 6.3 ms against
+    // 6.1 one lane per chain, 9 375 chains 4.0 against 3.5 four lanes per chain; profiles/r02/batch_size_sweep.txt)
+    (void)pair_ok;
+    return EPI_SHAPE_LANE;
+}
+// assume_packed: sizing / layout questions asked before epi_ekf_precheck_device has set path_hint (workspace bytes,
+// preferred lane_block) answer for the case that the batch will qualify for the packed kernels
+static int shape_of(const epi_batch_desc *d, bool assume_packed = false)
+{
+    const ModelInfo &mi = MODEL_TABLE[d->model];
+    if (d->storage) return EPI_SHAPE_LANE;
+    const bool packed = d->path_hint == 1 || (assume_packed && d->path_hint == 0);
+    return pick_shape(d->shape, mi.m, mi.generic != 0, d->B, monitor_hoisted(d) && packed);
+}
+
 static WsLayout ws_layout(const epi_batch_desc *d)
 {
     const int m = MODEL_TABLE[d->model].m;
@@ -824,7 +872,9 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.p_plus = take(!(om & EPI_OUT_P_PLUS), nP);
     // smoother intermediates of the generic models: X = pinv(P_MINUS) and its rank word per (step, chain)
     const bool generic = MODEL_TABLE[d->model].generic;
-    w.x = take(generic, (size_t)d->T * (m * (m + 1) / 2) * Bp * sizeof(double));   // packed upper triangle of X
+    // X: packed upper triangle, or all m*m rows where the two-lanes-per-chain smoother may read it (whole rows per lane)
+    const bool x_full = shape_of(d, true) == EPI_SHAPE_PAIR;
+    w.x = take(generic, (size_t)d->T * (x_full ? m * m : m * (m + 1) / 2) * Bp * sizeof(double));
     w.rank = take(generic, (size_t)d->T * Bp * sizeof(int32_t));
     w.flag = take(generic, 256);
     // ekf_monitor reads the fp64 innovations: workspace when the caller does not take them as an fp64 output
@@ -913,32 +963,6 @@ static int balanced_lanes(int cn, int waves_per_simd)
     return (int)(lw > kWave ? kWave : lw);
 }
 
-// Which lane mapping runs the 6-state generic models (epi_batch_desc.shape).  Auto: four lanes per chain while every
-// quad wavefront (16 chains) still gets a SIMD of its own, i.e. up to 16 384 chains on MI355X -- there the chains'
-// per-day latency is what counts and the quad kernels' instruction stream is half as long (9 375 chains: 3.9 instead of
-// 6.1 ms per pass); beyond that the quad waves (one per SIMD at ~290 registers) would run in rounds and one lane per
-// chain, the shape with the least total work, wins (18 750 chains: 7.1 against 9.0 ms).  profiles/r02/batch_size_sweep.txt.
-// EPIEKF_SHAPE=1|2 overrides (measurement).
-static int g_simd_count = 0;
-static int simd_count()
-{
-    if (!g_simd_count) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        g_simd_count = cus * 4;
-    }
-    return g_simd_count;
-}
-static bool use_quad(int shape, int m, bool generic, int B)
-{
-    if (m != 6 || !generic) return false;
-    if (const char *env = getenv("EPIEKF_SHAPE")) { const int v = atoi(env); if (v == 1 || v == 2) shape = v; }
-    if (shape == EPI_SHAPE_QUAD) return true;
-    if (shape == EPI_SHAPE_LANE) return false;
-    return ((long)B + kQC - 1) / kQC <= (long)simd_count();   // the quad waves still get a SIMD each (one round)
-}
-
 // the innovation monitor of a chain range as its own launch (after the forward kernel that wrote the innovations)
 template <int FLIP>
 static hipError_t launch_monitor(const KArgs &ka, int cn, hipStream_t st)
@@ -968,6 +992,28 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
     const bool run_sym = GENERIC && hint != 2, run_dense = !GENERIC || hint != 1;
     hipError_t e = hipSuccess;
     if constexpr (M == 6 && GENERIC) {
+        if (ka.pair && run_sym) {
+            // two lanes per chain: 32 chains per wavefront (ekf_pair.hpp); chosen only with path_hint = 1 and a hoisted monitor
+            const int pblocks = (cn + kPC - 1) / kPC;
+            const bool fast = ka.blk == kPC;
+            if (phase == 0 || phase == 1) {
+                if (fast) hipLaunchKernelGGL((ekf_fwd_pair<FLIP, kPC>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((ekf_fwd_pair<FLIP, 0>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                if ((e = launch_monitor<FLIP>(ka, cn, st)) != hipSuccess) return e;
+            }
+            if (!smooth) return e;
+            if (ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
+                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, st, ka);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
+            if (phase == 0 || phase == 2 || phase == 4) {
+                if (fast) hipLaunchKernelGGL((eks_bwd_pair<FLIP, kPC>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((eks_bwd_pair<FLIP, 0>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                e = hipGetLastError();
+            }
+            return e;
+        }
         if (ka.quad && run_sym) {
             // four lanes per chain: 16 chains per wavefront (ekf_quad.hpp); the dense fall-back keeps its own mapping
             const int qblocks = (cn + kQC - 1) / kQC;
@@ -1113,8 +1159,7 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
         // resumes from the S_MINUS / P_MINUS the previous one stored: same bits), and after each of them the eks_pinv grid
         // of ITS days starts on a second stream, beside the next forward segment.  Only the last segment's pinv is left
         // when the forward pass ends.  Not for a batch that fills the chip (nothing idles: measured level, round 1).
-        const bool quad = ka.quad != 0;
-        const long fwd_waves = quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
+        const long fwd_waves = ka.quad ? ((long)ka.B + kQC - 1) / kQC : ka.pair ? ((long)ka.B + kPC - 1) / kPC : ((long)ka.B + kWave - 1) / kWave;
         if (chunks == -3 || fwd_waves * 4 <= (long)simd_count() * 3) {
             constexpr int kTimeSeg = 4;
             LowPrioStream *lp = nullptr;
@@ -1271,7 +1316,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
     if (d->chunks < -3) { set_err(err, "chunks must be >= -3"); return EPI_ERR_BAD_ARG; }
     if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
-    if (d->shape < 0 || d->shape > 2) { set_err(err, "shape must be 0 (auto), 1 (lane per chain) or 2 (quad per chain)"); return EPI_ERR_BAD_ARG; }
+    if (d->shape < 0 || d->shape > 3) { set_err(err, "shape must be 0 (auto), 1 (lane), 2 (quad) or 3 (pair per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
@@ -1291,7 +1336,8 @@ int epi_ekf_preferred_lane_block(const epi_batch_desc *d)
     probe = *d; probe.lane_block = 0;
     if (epi_ekf_validate(&probe, nullptr) != EPI_OK) return 0;
     const ModelInfo &mi = MODEL_TABLE[d->model];
-    const int lw = (!d->storage && use_quad(d->shape, mi.m, mi.generic != 0, d->B)) ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2);
+    const int shp = shape_of(d, true);
+    const int lw = shp == EPI_SHAPE_QUAD ? kQC : shp == EPI_SHAPE_PAIR ? kPC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2);
     return lw < d->B ? lw : d->B;
 }
 
@@ -1328,7 +1374,10 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     KArgs ka{};
     ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode; ka.q_mode = d->q_mode;
     ka.blk = lane_block_of(d); ka.nblk = (d->B + ka.blk - 1) / ka.blk;
-    ka.quad = (!f32 && use_quad(d->shape, mi.m, mi.generic != 0, d->B)) ? 1 : 0;
+    const int shp = shape_of(d);
+    ka.quad = shp == EPI_SHAPE_QUAD ? 1 : 0;
+    ka.pair = shp == EPI_SHAPE_PAIR ? 1 : 0;
+    ka.x_full = ka.pair;
     ka.stor = f32 ? 1 : 0;
     ka.mf.lo_is_zero = mi.lo_is_zero; ka.mf.phi_ge = mi.phi_ge; ka.mf.obs_clamp = mi.obs_clamp;
     ka.mf.obs_type = mi.obs_fixed ? EPI_OBS_NEWCASES : d->obs_type;

@@ -141,15 +141,16 @@ typedef struct epi_batch_desc {
                              1 = one lane per chain (ekf_fwd_sym / eks_bwd_sym: least total work, what a batch that fills
                              the chip wants), 2 = four lanes per chain (ekf_fwd_quad / eks_bwd_quad: every 6 x 6 matrix as
                              a 2 x 2 grid of 3 x 3 blocks over a DPP quad; a ~2x shorter per-day instruction stream and
-                             4x the wavefronts, what a batch that does NOT fill the chip wants -- DESIGN.md 4).  Results
-                             are bit-identical either way.  Ignored by the other models. */
+                             4x the wavefronts, what a batch that does NOT fill the chip wants -- DESIGN.md 4), 3 = two lanes
+                             per chain (ekf_fwd_pair / eks_bwd_pair: rows 1-3 / 4-6 of every matrix; R_v a per-day series
+                             only, else 1 is used).  Results are bit-identical in all shapes.  Ignored by the other models. */
     int32_t storage;      /* element type of the OUTPUT arrays: 0 = fp64 (the reference's), 1 = fp32 storage with fp64
                              register arithmetic (BASELINE config 5): every selected output is the fp64 result rounded
                              once to fp32; the forward quantities the smoother reads back stay fp64 in the workspace.
                              epi_ekf_run_device only. */
 } epi_batch_desc;
 
-typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2 } epi_shape;
+typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_PAIR = 3 } epi_shape;
 
 typedef struct epi_inputs {
     const int32_t *x_series; /* [B] or NULL */

@@ -67,10 +67,10 @@ def build(draw):
     # process noise: diagonal (packed kernels) or full (dense fallback)
     if generic and draw(st.sampled_from([False, False, True])):
         w.Q = w.Q.copy(); w.Q[1] = 1e-13
-    lane_block = draw(st.sampled_from([0, 0, 3, 8, 16, "auto"]))
+    lane_block = draw(st.sampled_from([0, 0, 3, 8, 16, 32, "auto"]))
     chunks = draw(st.sampled_from([0, 0, 2, -2]))
     # lane mapping of the 6-state generic models: one lane per chain, four lanes per chain, or the library's own choice
-    shape = draw(st.sampled_from(["lane", "quad", "quad", "auto"]))
+    shape = draw(st.sampled_from(["lane", "quad", "quad", "pair", "pair", "auto"]))
     return w, lane_block, chunks, kind, shape
 
 
