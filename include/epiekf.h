@@ -178,7 +178,8 @@ size_t epi_ekf_workspace_bytes(const epi_batch_desc *d);        /* device scratc
 int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err);
 
 /* The lane_block that matches the way epi_ekf_run_device will launch this batch on the current device: the number of
- * chains one wavefront handles (64, or fewer when the launch is split into equally full rounds).  With it every
+ * chains one wavefront handles (64, or fewer when the launch is split into equally full rounds; 16 / 32 where the 6-state
+ * models run four / two lanes per chain, see `shape`).  With it every
  * wavefront's loads and stores of a step are one contiguous piece per array -- the fastest of the blocked layouts
  * (DESIGN.md 3).  Returns 0 for an invalid descriptor. */
 int epi_ekf_preferred_lane_block(const epi_batch_desc *d);

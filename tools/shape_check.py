@@ -1,4 +1,5 @@
-"""Quick parity check of the kernel variants against the oracle (development aid)."""
+"""Quick parity check of the three lane mappings and the launch modes against the oracle (GPU box; development aid):
+    PYTHONPATH=. python tools/shape_check.py"""
 import sys
 import numpy as np
 from epidemicmodeling_amd import batch, synth
