@@ -173,11 +173,19 @@ def lapack_reading_worker(job):
     """Worker of a process pool (spawn context: the children never touch the GPU): chains `cs` of Workload `w` through
     oracle/ekf_numpy.py -- the independent reading of the .m files that uses LAPACK's SVD for pinv, the closest thing to
     MATLAB's own built-in available here.  Returns the quantities the HIP-vs-LAPACK report compares."""
-    w, cs = job
+    w, cs = job[0], job[1]
+    one_ulp = len(job) > 2 and job[2]          # also: the same reading with every observation moved by one ulp ("*_1ulp")
+    if one_ulp:
+        w2 = w.select(np.arange(w.B))
+        w2.x = np.nextafter(w.x, np.inf)
     out = []
     for c in cs:
         nd = numpy_chain(w, int(c))
-        out.append({k: np.asarray(nd[k]) for k in ("S_MINUS", "S_PLUS", "S_SMOOTH", "u_opt_smooth", "pinv_rank")})
+        r = {k: np.asarray(nd[k]) for k in ("S_MINUS", "S_PLUS", "S_SMOOTH", "u_opt_smooth", "pinv_rank") if k in nd}
+        if one_ulp:
+            n2 = numpy_chain(w2, int(c))
+            r.update({k + "_1ulp": np.asarray(n2[k]) for k in ("S_MINUS", "S_PLUS")})
+        out.append(r)
     return out
 
 
