@@ -51,11 +51,9 @@ def parse():
     ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg3", "cfg5", "newcase"])
     ap.add_argument("--outputs", default="all", choices=["all", "reduced"],
                     help="reduced = u_opt_smooth + S_SMOOTH only (what TrainPredictPrescribeNPI.m:460-493 consumes)")
-    ap.add_argument("--chunks", type=int, default=0,
-                    help="chain chunks a full call is split into (helper streams; DESIGN.md); 0/1 (default) = single "
-                         "stream, one launch per kernel and pass, so that rocprofv3's per-kernel averages and the HIP-event "
-                         "averages of this script describe the same launches; -1 = whole one-wave-per-SIMD rounds + a tail "
-                         "chunk whose kernels run beside the main chunk's eks_pinv grid (about 1 ms per pass faster)")
+    ap.add_argument("--time-pipe", type=int, default=0, choices=[-1, 0, 1],
+                    help="epi_batch_desc.time_pipe: 0 = the library decides whether the forward kernel runs in time segments "
+                         "with the pinv grid of each beside the next (it does for batches that leave SIMDs idle), 1 = on, -1 = off")
     ap.add_argument("--lane-block", type=int, default=-1,
                     help="output layout (epi_batch_desc.lane_block): -1 = chain-blocked with one block per wavefront of the "
                          "launch (epi_ekf_preferred_lane_block; default), n > 0 = blocks of n chains, 0 = classic [T][rows][B]")
@@ -64,7 +62,7 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the fixed sweep sharded over the ranks (default); weak = every rank a full sweep "
                          "of its own regions")
-    ap.add_argument("--shape", default="auto", choices=["auto", "lane", "quad", "pair"],
+    ap.add_argument("--shape", default="auto", choices=["auto", "lane", "quad"],
                     help="lane mapping of the 6-state kernels (epi_batch_desc.shape): auto = by batch size")
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="f32 = BASELINE config 5's fp32: outputs STORED as float32, arithmetic and the smoother's inputs fp64 "
@@ -177,8 +175,32 @@ def cpu_baseline(w, args):
             "single_thread": {"value": w1.B * w1.T / dt1, "cores": 1, "sample": f"{w1.B} chains x {w1.T} days, {dt1:.1f} s"}}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE): start the N ranks as fresh child processes -- one
+    torch.distributed.run on 127.0.0.1 with a free port, same arguments -- BEFORE this process has imported torch or
+    touched a GPU, relay their output (rank 0 prints the one JSON line) and return the launcher's exit code, which is
+    non-zero as soon as any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     import torch
     import torch.distributed as dist
     from epidemicmodeling_amd import batch
@@ -187,8 +209,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (or start bench.py bare)")
     # one process per GPU; EPI_BENCH_BACKEND=gloo + fewer devices than ranks is only for rehearsing the N > 1
     # code path on a one-GPU box (ranks then share device 0 and the gather goes through host memory)
     backend = os.environ.get("EPI_BENCH_BACKEND", "nccl")
@@ -216,7 +237,7 @@ def main():
     m = w.m
     outputs = None if args.outputs == "all" else ["u_opt_smooth", "S_SMOOTH"]
     dw = batch.DeviceWorkload(w, dev)
-    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, chunks=args.chunks, lane_block="auto" if args.lane_block < 0 else args.lane_block,
+    runner = batch.EkfRunner(dw, outputs=outputs, extras=False, time_pipe=args.time_pipe, lane_block="auto" if args.lane_block < 0 else args.lane_block,
                              shape=args.shape, storage=args.storage)
     steps_per_pass = w.B * w.T
     t_hist_idx = w.meta.get("T_hist", w.T) - 1
@@ -238,34 +259,46 @@ def main():
         sp[batch.SIM_W:batch.SIM_W + n] = 1.0                       # npi_weights = ones (testPrescribeXPRIZE02.m:56)
         S = runner.unblocked("S_SMOOTH")
         th = t_hist_idx + 1
-        # historic prefixes are inputs of the scoring step (in the reference they come from the 3-state run of the
-        # region); computed once, outside the timed region
+        # The scoring step's inputs -- s/i/alpha_historic(end) and the historic prefixes of the two NPICost sums -- come
+        # from the region's 3-state run in the reference (TrainPredictPrescribeNPI.m:351-362, 481); here they are taken
+        # once, outside the timed region, from the smoothed states of the first pass.
+        sp[0:3].copy_(runner.unblocked_at("S_SMOOTH", t_hist_idx)[0:3])
         score_state["J0p"] = (S[:th, 0] * S[:th, 1] * S[:th, 2]).sum(dim=0)
         score_state["J1p"] = runner.unblocked("u_opt_smooth")[:th].sum(dim=(0, 1))
         score_state["sp"] = sp
 
     def one_step(events=None):
-        if events is None:
-            runner.run()                      # the call a user makes: forward + pinv + backward
-        else:                                 # same work, one kernel stage per call, bracketed by HIP events
-            e0, e1, e2, e3 = events
-            e0.record(); runner.run(phase=1); e1.record(); runner.run(phase=3); e2.record()
-            runner.run(phase=4); e3.record()
+        """One pass of the hot path.  events None: what a user calls -- ONE library call (epi_sweep_run_device: forward
+        kernel, pinv grid, smoother, and beside the smoother's pass over the observed days the scoring tail and the
+        Pareto filter).  With events: the same work enqueued stage by stage, bracketed by HIP events."""
+        whole = not strong                 # this rank holds whole regions: the library filters the front too
+        if events is None and score and score_state:
+            sc = runner.run_sweep(t_hist_idx + 1, score_state["sp"], score_state["J0p"], score_state["J1p"],
+                                  n_regions=w.Sx if whole else None)
+            if whole:
+                score_state["front"] = (sc["on_front"], sc["i_opt"])
+        else:
+            if events is None:
+                runner.run()
+            else:
+                e0, e1, e2, e3 = events
+                e0.record(); runner.run(phase=1); e1.record(); runner.run(phase=3); e2.record()
+                runner.run(phase=4); e3.record()
+            sc = None
+            if score and score_state:
+                sc = batch.score_sweep(runner.out["u_opt_smooth"], t_hist_idx + 1, score_state["sp"], score_state["J0p"],
+                                       score_state["J1p"], B=w.B)
+                if whole:
+                    score_state["front"] = batch.pareto_front(sc["J0"], sc["J1"], w.Sx)
         if score and score_state:
-            sp = score_state["sp"]
-            sp[0:3].copy_(runner.unblocked_at("S_SMOOTH", t_hist_idx)[0:3])
-            sc = batch.score_sweep(runner.out["u_opt_smooth"], t_hist_idx + 1, sp, score_state["J0p"], score_state["J1p"], B=w.B)
-            # Pareto-front filter + optimum per region (TrainPredictPrescribeNPI.m:624-633), still on the device
             if strong:
                 # a region's 250 cost weights may straddle two ranks: (J0, J1) of all shards are gathered to rank 0
                 # (the path's only collective; shards padded to the common block length) and filtered there
                 allj = batch.gather_shards_to_root(torch.stack([sc["J0"], sc["J1"]]), B_total)
                 if rank == 0:
                     score_state["front"] = batch.pareto_front(allj[0].contiguous(), allj[1].contiguous(), regions_total)
-            else:
-                score_state["front"] = batch.pareto_front(sc["J0"], sc["J1"], w.Sx)
-                if world > 1:
-                    batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
+            elif world > 1:
+                batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
         elif world > 1:
             # no scoring: gather the per-chain smoothed state at the last observed day to rank 0
             batch.gather_to_root(runner.unblocked_at("S_SMOOTH", t_hist_idx).contiguous())
@@ -280,14 +313,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    # the timed region: K passes, each enqueued stage by stage (the same three kernels `runner.run()` launches in one
-    # call) so that HIP events on the launch stream bracket every kernel INSIDE the region the wall clock times
-    # (the chunked modes overlap the stages of different chunks inside ONE call, so there the timed passes use that one
-    # call and the per-kernel durations come from K further passes enqueued stage by stage)
+    # The timed passes are the call a user makes (one epi_sweep_run_device per pass): inside it the library overlaps what is
+    # off the critical path (monitor, scoring tail, Pareto filter; for a batch that leaves SIMDs idle also the pinv grids of
+    # the forward pass's time segments).  The per-kernel durations come from K further passes enqueued stage by stage, each
+    # bracketed by HIP events on the launch stream.  EPI_BENCH_STAGED=1: time the staged passes instead (round-1 behaviour).
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    # The timed passes are the call a user makes (one epi_ekf_run_device per pass): inside it the library may overlap the
-    # stages (the pipelined-in-time launch of a batch that leaves SIMDs idle).  The per-kernel durations come from K further
-    # passes enqueued stage by stage.  EPI_BENCH_STAGED=1: time the staged passes instead (round-1 behaviour).
     staged = os.environ.get("EPI_BENCH_STAGED") == "1"
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -335,8 +365,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (strong or world == 1) and args.scaling == "strong" else "weak",
             "vs_baseline": None, "dtype": "f64" if args.storage == "f64" else "f64 arithmetic, f32 storage", "data": "synthetic",
-            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "chunks": args.chunks,
-                       "lane_block": runner.blk, "shape": ("quad (4 lanes per chain)" if runner.blk == 16 else "pair (2 lanes per chain)" if runner.blk == 32 else "lane (1 lane per chain)") if m == 6 else "lane (1 lane per chain)",
+            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "time_pipe": args.time_pipe,
+                       "lane_block": runner.blk, "shape": ("quad (4 lanes per chain)" if runner.blk == 16 else "lane (1 lane per chain)") if m == 6 else "lane (1 lane per chain)",
                        "sweep_chains_total": B_total,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),

@@ -13,13 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # EPIEKF_LIB: load another build of the same ABI instead (A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 
-ABI_VERSION = 2      # EPIEKF_ABI_VERSION of include/epiekf.h
+ABI_VERSION = 3      # EPIEKF_ABI_VERSION of include/epiekf.h
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_ekf_run_host_multi", "epi_host_pool_release", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_npi_cost_device", "epi_si_controlled_device", "epi_si_controlled_host", "epi_sialpha_sim_host", "epi_seirp_sim_host", "epi_npi_cost_host", "epi_calib_copy_f64_device",
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
     "epi_preprocess_workspace_bytes", "epi_preprocess_device", "epi_nnls_affine_fit_device",
+    "epi_sweep_run_device", "epi_sweep_prescribe_host", "epi_preprocess_host", "epi_nnls_affine_fit_host", "epi_random_npi_mc_host",
 ]
 
 
@@ -35,7 +36,7 @@ class EpiError(RuntimeError):
 class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "model", "B", "T", "Sx", "Su", "n_npi", "L", "order",
                                           "obs_type", "r_mode", "q_mode")] + [
-        ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("chunks", C.c_int32),
+        ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("time_pipe", C.c_int32),
         ("lane_block", C.c_int32), ("shape", C.c_int32), ("storage", C.c_int32)]
 
 
@@ -48,6 +49,24 @@ class Outputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "P_MINUS",
                                            "P_PLUS", "P_SMOOTH", "K_GAIN", "innovations", "rho", "pinv_rank",
                                            "status")]
+
+
+class SweepDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "R", "P", "t_hist")]
+
+
+class PrescribeDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("abi_version", "R", "P", "T", "t_hist", "n_npi", "L", "order", "obs_type")] + [
+        ("out_mask", C.c_uint32), ("shape", C.c_int32), ("time_pipe", C.c_int32)]
+
+
+class PrescribeInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x", "u", "R_series", "prm", "s_init", "Ps_init", "s_final", "Ps_final", "Q", "eps",
+                                           "sp", "J0_prefix", "J1_prefix")]
+
+
+class PrescribeOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("J0", "J1", "on_front", "i_opt", "u_opt", "S_opt")] + [("extras", Outputs)]
 
 
 class SimDesc(C.Structure):
@@ -178,6 +197,18 @@ def lib():
         h.epi_ekf_run_host_multi.restype = C.c_int
         h.epi_ekf_run_host_multi.argtypes = [C.POINTER(BatchDesc), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_char_p]
         h.epi_host_pool_release.restype = None
+        h.epi_sweep_run_device.restype = C.c_int
+        h.epi_sweep_run_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p, C.c_size_t,
+                                           C.POINTER(SweepDesc)] + [C.c_void_p] * 7 + [C.c_void_p, C.c_char_p]
+        h.epi_sweep_prescribe_host.restype = C.c_int
+        h.epi_sweep_prescribe_host.argtypes = [C.POINTER(PrescribeDesc), C.POINTER(PrescribeInputs), C.POINTER(PrescribeOutputs),
+                                               C.c_int, C.POINTER(C.c_int), C.c_char_p]
+        h.epi_preprocess_host.restype = C.c_int
+        h.epi_preprocess_host.argtypes = [C.POINTER(PreDesc)] + [C.c_void_p] * 4 + [C.POINTER(PreOutputs), C.c_int, C.c_char_p]
+        h.epi_nnls_affine_fit_host.restype = C.c_int
+        h.epi_nnls_affine_fit_host.argtypes = [C.POINTER(NnlsDesc)] + [C.c_void_p] * 7 + [C.c_int, C.c_char_p]
+        h.epi_random_npi_mc_host.restype = C.c_int
+        h.epi_random_npi_mc_host.argtypes = [C.POINTER(McDesc)] + [C.c_void_p] * 8 + [C.c_int, C.c_char_p]
         if h.epi_abi_version() != ABI_VERSION:
             raise ImportError("libepiekf.so ABI version mismatch")
         _lib = h
@@ -201,5 +232,5 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask,
     else:
         d.obs_type = int(obs_type)
     d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), int(q_mode), int(out_mask), 0
-    d.path_hint, d.chunks, d.lane_block, d.shape, d.storage = 0, 0, 0, 0, 0
+    d.path_hint, d.time_pipe, d.lane_block, d.shape, d.storage = 0, 0, 0, 0, 0
     return d

@@ -61,10 +61,10 @@ class DeviceWorkload:
 class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
-    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, chunks=0, precheck=True, lane_block=0, shape=0,
+    def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, time_pipe=0, precheck=True, lane_block=0, shape=0,
                  storage="f64"):
-        """chunks > 1: a full run() is split into that many chain chunks on helper streams (overlaps the
-        (chain, step)-parallel pinv grid with the sequential kernels of the other chunks).  precheck: ask the
+        """time_pipe: epi_batch_desc.time_pipe (0 = the library decides whether a full call runs its forward kernel in time
+        segments with the pinv grid of each segment beside the next, 1 = on, -1 = off).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
         run() enqueues only the variant that will actually execute.  lane_block: 0 = classic [T][rows][B] outputs;
         8 / "auto" (= chains per wavefront of the launch) = chain-blocked outputs (epi_batch_desc.lane_block): `out` then holds the raw blocked tensors
@@ -77,8 +77,8 @@ class EkfRunner:
         self.mask = out_mask_of(names)
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
                                    dw.r_mode, self.mask, dw.q_mode)
-        # epi_batch_desc.shape: 0 = by batch size, 1 / 2 / 3 = one / four / two lanes per chain (6-state generic models)
-        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2, "pair": 3}.get(shape, shape)
+        # epi_batch_desc.shape: 0 = by batch size, 1 / 2 = one / four lanes per chain (6-state generic models)
+        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2}.get(shape, shape)
         # epi_batch_desc.storage: "f32" = outputs stored as float32 (each the fp64 result rounded once; BASELINE config 5)
         self.desc.storage = {"f64": 0, "f32": 1}[storage]
         odt = torch.float32 if storage == "f32" else torch.float64
@@ -104,7 +104,8 @@ class EkfRunner:
         self.ws_bytes = int(h.epi_ekf_workspace_bytes(C.byref(self.desc)))
         self.ws = torch.empty((max(self.ws_bytes, 8) + 7) // 8, dtype=torch.float64, device=dev)
         self.ins = dw.inputs_struct()
-        self.desc.chunks = int(chunks)
+        self.desc.time_pipe = int(time_pipe)
+        self._sweep = None
         if precheck:
             ok = C.c_int(0)
             st = torch.cuda.current_stream(dev)
@@ -127,6 +128,35 @@ class EkfRunner:
                                            _ptr(self.ws), self.ws_bytes, C.c_void_p(st.cuda_stream), self.err)
         _lib.check(rc, self.err)
         return self.out
+
+    def run_sweep(self, t_hist, sp, J0_prefix, J1_prefix, n_regions=None, stream=None):
+        """epi_sweep_run_device: the full filter call followed by the sweep's scoring tail (TrainPredictPrescribeNPI.m:
+        481-493) on the last T - t_hist days of the u_opt_smooth it wrote and, when `n_regions` is given (the batch then
+        holds n_regions x P chains, region-major), the Pareto filter and optimum per region (:624-633) -- one library
+        call, scoring and filter enqueued beside the smoother's pass over the observed days.  sp [48, B], J0_prefix /
+        J1_prefix [B] as for score_sweep.  Returns dict J0, J1 [B] (+ on_front bool-able int32 [R, P], i_opt int32 [R])."""
+        dev = self.dw.device
+        B = self.dw.B
+        if self._sweep is None:
+            self._sweep = {"J0": torch.empty((B,), dtype=torch.float64, device=dev), "J1": torch.empty((B,), dtype=torch.float64, device=dev)}
+        res = self._sweep
+        sd = _lib.SweepDesc()
+        sd.abi_version, sd.t_hist = _lib.ABI_VERSION, int(t_hist)
+        if n_regions:
+            P = B // int(n_regions)
+            if P * int(n_regions) != B:
+                raise ValueError("the batch does not hold the same number of cost weights for every region")
+            sd.R, sd.P = int(n_regions), P
+            if "on_front" not in res:
+                res["on_front"] = torch.empty((int(n_regions), P), dtype=torch.int32, device=dev)
+                res["i_opt"] = torch.empty((int(n_regions),), dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev) if stream is None else stream
+        rc = _lib.lib().epi_sweep_run_device(C.byref(self.desc), C.byref(self.ins), C.byref(self.outs), _ptr(self.ws), self.ws_bytes,
+                                             C.byref(sd), _ptr(sp), _ptr(J0_prefix), _ptr(J1_prefix), _ptr(res["J0"]), _ptr(res["J1"]),
+                                             _ptr(res.get("on_front")) if n_regions else None,
+                                             _ptr(res.get("i_opt")) if n_regions else None, C.c_void_p(st.cuda_stream), self.err)
+        _lib.check(rc, self.err)
+        return res
 
     def unblocked(self, name):
         """[T, rows, B] ([T, B]) tensor of output `name` whatever the layout run() wrote it in."""
@@ -152,10 +182,10 @@ class EkfRunner:
         return sum(t.numel() * t.element_size() for t in self.out.values())
 
 
-def run_workload(w, outputs=None, device="cuda:0", extras=True, chunks=0, precheck=True, lane_block=0, shape=0, storage="f64"):
+def run_workload(w, outputs=None, device="cuda:0", extras=True, time_pipe=0, precheck=True, lane_block=0, shape=0, storage="f64"):
     """Convenience: upload `w`, run once, return dict name -> numpy array [T, rows, B] (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
-    r = EkfRunner(dw, outputs, extras=extras, chunks=chunks, precheck=precheck, lane_block=lane_block, shape=shape, storage=storage)
+    r = EkfRunner(dw, outputs, extras=extras, time_pipe=time_pipe, precheck=precheck, lane_block=lane_block, shape=shape, storage=storage)
     r.run()
     torch.cuda.synchronize(dw.device)
     res = {n: r.unblocked(n).cpu().numpy() for n in r.out}
@@ -175,11 +205,10 @@ def shard_chains(B: int, rank: int, world: int):
 
 def gather_to_root(t: torch.Tensor, group=None, dst: int = 0):
     """The path's only collective: gather per-rank result shards (chain-minor tensors of equal shape)
-    to rank `dst` at the end of a sweep.  Over RCCL this is one send per peer on its own xGMI link."""
+    to rank `dst` at the end of a sweep.  Over RCCL this is one send per peer on its own xGMI link.  The collective is
+    issued whatever the world size (a one-rank world runs it too: same code path as N ranks)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
-        return [t]
     if dist.get_backend(group) != "nccl":
         t = t.cpu()                     # gloo rehearsal / CPU tests: the gather goes through host memory
     bufs = [torch.empty_like(t) for _ in range(world)] if dist.get_rank(group) == dst else None
@@ -198,9 +227,9 @@ def gather_shards_to_root(t: torch.Tensor, B_total: int, group=None, dst: int = 
     if t.shape[-1] < per:
         t = torch.nn.functional.pad(t, (0, per - t.shape[-1]))
     t = t.contiguous()
-    if world > 1 and dist.get_backend(group) == "nccl":
+    if dist.get_backend(group) == "nccl":
         # RCCL: one ncclAllGather of the small per-chain summaries (16 B per chain) -- every rank receives
-        # them, rank `dst` uses them
+        # them, rank `dst` uses them.  Issued for every world size, one rank included.
         buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(buf, t, group=group)
         if dist.get_rank(group) != dst:

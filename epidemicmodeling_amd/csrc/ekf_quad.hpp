@@ -685,34 +685,52 @@ __global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *
     qload_prm(p, np, a, B, c, Q, galds + Q.lc);
     const QOff o36 = qoffsets<BLK>(Q, lay, true), o21 = qoffsets<BLK>(Q, lay, false);
 
-    // terminal conditions GenericEKF.m:189-202 (Ps_final symmetric in values and NaN pattern: ekf_precheck)
+    // smoother steps of this launch: k = k_from down to k_to (see eks_bwd_sym); k_from = T - 2 starts from the terminal
+    // condition, a later launch resumes from the hand-over rows (every lane of the quad its own 3 x 3 block)
+    const int k_from = a.bk_from, k_to = a.bk_to;
+    const size_t hp = (size_t)a.hand_pitch;
+    int st_guard = 0, st_cap = 0, min_rank = M;
     double Ss[M];
     blk3 Ps;
     const int tT = tpos<FLIP>(T - 1, T);
-    qload_vec<BLK>(a.S_PLUS, tT, lay, Ss);
+    if (k_from < T - 2) {
 #pragma unroll
-    for (int i = 0; i < M; i++) {
-        const double f = a.s_final[(size_t)i * B + c];
-        if (!is_nan(f)) Ss[i] = f;
-    }
-    qload_sym_blk(a.P_PLUS, tT, lay, o36, 36, Ps);
+        for (int i = 0; i < M; i++) Ss[i] = a.hand_s[(size_t)i * hp + c];
 #pragma unroll
-    for (int r = 0; r < 3; r++)
+        for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) {
-            const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + cc;
-            const double f = a.Ps_final[(size_t)(i < j ? IXM(i, j) : IXM(j, i)) * B + c];
-            if (!is_nan(f)) Ps[r][cc] = f;
+            for (int cc = 0; cc < 3; cc++) {
+                const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + cc;
+                Ps[r][cc] = a.hand_p[(size_t)IXM(i, j) * hp + c];
+            }
+        const int word = a.hand_i[c];
+        st_guard = word & 1; st_cap = (word >> 1) & 1; min_rank = word >> 8;
+    } else {
+        // terminal conditions GenericEKF.m:189-202 (Ps_final symmetric in values and NaN pattern: ekf_precheck)
+        qload_vec<BLK>(a.S_PLUS, tT, lay, Ss);
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const double f = a.s_final[(size_t)i * B + c];
+            if (!is_nan(f)) Ss[i] = f;
         }
-    qstore_vec<BLK>(a.S_SMOOTH, tT, lay, Q, Ss);
-    qstore_blk<BLK>(a.P_SMOOTH, tT, lay, Q, Ps);
-    if (a.u_opt_smooth) {
-        const double z[3] = {0.0, 0.0, 0.0};
-        qstore_u<BLK>(a.u_opt_smooth, a, tT, lay, Q, z);
+        qload_sym_blk(a.P_PLUS, tT, lay, o36, 36, Ps);
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + cc;
+                const double f = a.Ps_final[(size_t)(i < j ? IXM(i, j) : IXM(j, i)) * B + c];
+                if (!is_nan(f)) Ps[r][cc] = f;
+            }
+        qstore_vec<BLK>(a.S_SMOOTH, tT, lay, Q, Ss);
+        qstore_blk<BLK>(a.P_SMOOTH, tT, lay, Q, Ps);
+        if (a.u_opt_smooth) {
+            const double z[3] = {0.0, 0.0, 0.0};
+            qstore_u<BLK>(a.u_opt_smooth, a, tT, lay, Q, z);
+        }
+        qstore_scalar(a.pinv_rank, tT, lay, (int32_t)-1);
     }
-    qstore_scalar(a.pinv_rank, tT, lay, (int32_t)-1);
 
-    int st_guard = 0, st_cap = 0, min_rank = M;
     // Everything step k reads is requested one iteration ahead (EPI_QUAD_BWD_PF): a lone wave then never sits through a
     // memory round trip at the top of a step.  Two register sets used alternately (the loop body exists twice), so the
     // prefetched values are consumed where they landed -- copying them costs more than the latency (measured).
@@ -836,23 +854,36 @@ __global__ __launch_bounds__(kWave) void eks_bwd_quad(const KArgs a, const int *
 #if EPI_QUAD_BWD_PF
     {
         In bufA, bufB;
-        int k = T - 2;
-        if (k >= 0) fetch(k, bufA);
-        while (k >= 0) {
-            if (k > 0) fetch(k - 1, bufB);
+        int k = k_from;
+        if (k >= k_to) fetch(k, bufA);
+        while (k >= k_to) {
+            if (k > k_to) fetch(k - 1, bufB);
             step(k, bufA);
-            if (--k < 0) break;
-            if (k > 0) fetch(k - 1, bufA);
+            if (--k < k_to) break;
+            if (k > k_to) fetch(k - 1, bufA);
             step(k, bufB);
             --k;
         }
     }
 #else
-    for (int k = T - 2; k >= 0; k--) {
+    for (int k = k_from; k >= k_to; k--) {
         In cur;
         fetch(k, cur);
         step(k, cur);
     }
 #endif
-    if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+    if (k_to > 0) {        // hand-over to the launch that continues with step k_to - 1
+        if (Q.q == 0) {
+#pragma unroll
+            for (int i = 0; i < M; i++) a.hand_s[(size_t)i * hp + c] = Ss[i];
+            a.hand_i[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                const int i = (Q.bi ? 3 : 0) + r, j = (Q.bj ? 3 : 0) + cc;
+                a.hand_p[(size_t)IXM(i, j) * hp + c] = Ps[r][cc];
+            }
+    } else if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }

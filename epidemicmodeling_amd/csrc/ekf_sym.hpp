@@ -436,37 +436,53 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
 #pragma unroll
     for (int i = 0; i < M; i++) Qd[i] = a.Q[(size_t)IXM(i, i) * B + c];
 
+    // Smoother steps of this launch: k = k_from down to k_to (launch_chain may cut the recursion in two so that the
+    // sweep's scoring tail starts once the horizon days are final).  k_from = T - 2 starts from the terminal condition; a
+    // later launch resumes from what the previous one left in the hand-over rows.
+    const int k_from = a.bk_from, k_to = a.bk_to;
+    const size_t hp = (size_t)a.hand_pitch;
+    int st_guard = 0, st_cap = 0, min_rank = M;
     // terminal conditions GenericEKF.m:189-202.  Ps_final overrides entry by entry; ekf_precheck guarantees it
     // is symmetric (values and NaN pattern), so P_SMOOTH(:,:,T) is symmetric and stays packed.
     double Ss[M], Ps[NS];
     const int tT = tpos<FLIP>(T - 1, T);
-    load_vec<M>(a.S_PLUS, tT, lay, Ss);
+    if (k_from < T - 2) {
 #pragma unroll
-    for (int i = 0; i < M; i++) {
-        const double f = a.s_final[(size_t)i * B + c];
-        if (!is_nan(f)) Ss[i] = f;
-    }
-    load_sym<M>(a.P_PLUS, tT, lay, Ps);
+        for (int i = 0; i < M; i++) Ss[i] = a.hand_s[(size_t)i * hp + c];
 #pragma unroll
-    for (int j = 0; j < M; j++)
+        for (int j = 0; j < M; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) {
-            const double f = a.Ps_final[(size_t)IXM(i, j) * B + c];
-            if (!is_nan(f)) Ps[sidx(i, j)] = f;
+            for (int i = 0; i <= j; i++) Ps[sidx(i, j)] = a.hand_p[(size_t)IXM(i, j) * hp + c];
+        const int word = a.hand_i[c];
+        st_guard = word & 1; st_cap = (word >> 1) & 1; min_rank = word >> 8;
+    } else {
+        load_vec<M>(a.S_PLUS, tT, lay, Ss);
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const double f = a.s_final[(size_t)i * B + c];
+            if (!is_nan(f)) Ss[i] = f;
         }
-    store_vec<M>(a.S_SMOOTH, tT, lay, Ss);
-    store_sym<M>(a.P_SMOOTH, tT, lay, Ps);
-    if (STOR) { store_rows_f32<M>(a.f.S_SMOOTH, tT, M, lay, Ss); store_sym_f32<M>(a.f.P_SMOOTH, tT, lay, Ps); }
-    if (a.u_opt_smooth || (STOR && a.f.u_opt_smooth)) {
-        double z[kNpi];
+        load_sym<M>(a.P_PLUS, tT, lay, Ps);
 #pragma unroll
-        for (int k = 0; k < kNpi; k++) z[k] = 0.0;
-        store_u(a.u_opt_smooth, a, tT, lay, z);
-        if (STOR) store_rows_f32<kNpi>(a.f.u_opt_smooth, tT, (unsigned)a.n_npi, lay, z);
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i <= j; i++) {
+                const double f = a.Ps_final[(size_t)IXM(i, j) * B + c];
+                if (!is_nan(f)) Ps[sidx(i, j)] = f;
+            }
+        store_vec<M>(a.S_SMOOTH, tT, lay, Ss);
+        store_sym<M>(a.P_SMOOTH, tT, lay, Ps);
+        if (STOR) { store_rows_f32<M>(a.f.S_SMOOTH, tT, M, lay, Ss); store_sym_f32<M>(a.f.P_SMOOTH, tT, lay, Ps); }
+        if (a.u_opt_smooth || (STOR && a.f.u_opt_smooth)) {
+            double z[kNpi];
+#pragma unroll
+            for (int k = 0; k < kNpi; k++) z[k] = 0.0;
+            store_u(a.u_opt_smooth, a, tT, lay, z);
+            if (STOR) store_rows_f32<kNpi>(a.f.u_opt_smooth, tT, (unsigned)a.n_npi, lay, z);
+        }
+        if (a.pinv_rank) a.pinv_rank[lay_scalar(tT, lay)] = -1;
     }
-    if (a.pinv_rank) a.pinv_rank[lay_scalar(tT, lay)] = -1;
 
-    int st_guard = 0, st_cap = 0, min_rank = M;
     // Software pipeline.  Vector-memory operations retire in issue order, so loads issued after a step's
     // stores would wait for those stores to drain.  The results of a step are therefore kept in registers
     // (they are the recursion state anyway) and stored at the top of the NEXT iteration, right after that
@@ -508,9 +524,9 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     BwdIn<M> nxt;
     auto step = [&](int k) {
         const int t = tpos<FLIP>(k, T);
-        if (PF & 1) { if (k > 0) fetch_small(k - 1, nxt); } else fetch_small(k, cur);
-        if (PF & 2) { if (k > 0) fetch_pp(k - 1, nxt); } else fetch_pp(k, cur);
-        if (PF & 4) { if (k > 0) fetch_x(k - 1, nxt); } else fetch_x(k, cur);
+        if (PF & 1) { if (k > k_to) fetch_small(k - 1, nxt); } else fetch_small(k, cur);
+        if (PF & 2) { if (k > k_to) fetch_pp(k - 1, nxt); } else fetch_pp(k, cur);
+        if (PF & 4) { if (k > k_to) fetch_x(k - 1, nxt); } else fetch_x(k, cur);
         flush();
         // s(k+1|k) and P(k+1|k): read back at their point of use, or (EPI_BWD_RECOMPUTE) recomputed from the stored
         // s(k|k), P(k|k), u(:,k) with the forward kernel's own functions (:155-164) -- bit-identical either way
@@ -634,11 +650,19 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
             for (int e = 0; e < M * M; e++) cur.X[e] = nxt.X[e];
         }
     };
-    if ((PF & 1) && T >= 2) fetch_small(T - 2, cur);
-    if ((PF & 2) && T >= 2) fetch_pp(T - 2, cur);
-    if ((PF & 4) && T >= 2) fetch_x(T - 2, cur);
-    for (int k = T - 2; k >= 0; k--) step(k);
+    if ((PF & 1) && k_from >= k_to) fetch_small(k_from, cur);
+    if ((PF & 2) && k_from >= k_to) fetch_pp(k_from, cur);
+    if ((PF & 4) && k_from >= k_to) fetch_x(k_from, cur);
+    for (int k = k_from; k >= k_to; k--) step(k);
     flush();
-    if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+    if (k_to > 0) {        // hand-over to the launch that continues with step k_to - 1
+#pragma unroll
+        for (int i = 0; i < M; i++) a.hand_s[(size_t)i * hp + c] = Ss[i];
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i <= j; i++) a.hand_p[(size_t)IXM(i, j) * hp + c] = Ps[sidx(i, j)];
+        a.hand_i[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+    } else if (a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }
 

@@ -12,6 +12,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <tuple>
 #include <vector>
 #include "ekf_device.hpp"
@@ -60,14 +66,19 @@ struct KArgs {
     // bound by HBM / per-CU memory throughput, which scales with active lanes, not by wave count.
     int lw;
     int quad;   // 6-state generic models: four lanes per chain (ekf_quad.hpp) instead of one
-    int pair;   // ... two lanes per chain (ekf_pair.hpp)
-    int x_full; // eks_pinv stores X with all 36 rows (the pair smoother reads whole rows) instead of the packed upper triangle
     // epi_batch_desc.storage = 1: the caller's outputs are fp32 arrays (same layouts, 4-byte elements); each selected
     // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
     // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
     int stor;   // 1: fp32 storage (see F32 below)
     int k_begin, k_end;   // filter steps [k_begin, k_end) of this forward launch (k_end <= 0: up to T); eks_pinv: steps from pinv_step0
     int pinv_step0;
+    // smoother steps of this backward launch (packed / quad kernels): k = bk_from, bk_from - 1, ..., bk_to.  bk_from = T - 2
+    // starts from the terminal condition (:189-202); a later launch resumes from the S_SMOOTH / P_SMOOTH / status word the
+    // previous one left in the hand-over workspace (hand_s [m][Bp], hand_p [m*m][Bp], hand_i [Bp]) -- the same bits
+    int bk_from, bk_to;
+    double *hand_s, *hand_p;
+    int32_t *hand_i;
+    int hand_pitch;       // Bp: chains the hand-over rows are sized for
     int mon_defer;   // 1: this launch does not enqueue ekf_monitor itself (the caller does, later)
     int mon_hoist;   // 1: the packed / quad forward kernels skip the innovation monitor, ekf_monitor replays it (r_mode 1)
     struct F32 { float *u_opt, *u_opt_smooth, *S_MINUS, *S_PLUS, *S_SMOOTH, *P_MINUS, *P_PLUS, *P_SMOOTH, *K_GAIN, *innovations, *rho; } f;
@@ -457,12 +468,7 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     constexpr int BZS = (M >= 6) ? pinv_wg<M>() : 0;
     __shared__ double bzs[BZS ? 2 * M * BZS : 1];
     const int rank = sym_pinv<M, BZS>(P, X, &capped, bzs + threadIdx.x);           // :215
-    if (a.x_full) {
-        unsigned voff, rowb;
-        const rsrc_t r = lay_slice(a.X, t1, M * M, lay, voff, rowb);
-#pragma unroll
-        for (int e = 0; e < M * M; e++) bst(r, voff, (unsigned)e * rowb, X[e]);
-    } else {   // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
+    {   // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
         constexpr int NSX = M * (M + 1) / 2;
         unsigned voff, rowb;
         const rsrc_t r = lay_slice(a.X, t1, NSX, lay, voff, rowb);
@@ -621,7 +627,6 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 
 #include "ekf_sym.hpp"
 #include "ekf_quad.hpp"
-#include "ekf_pair.hpp"
 
 // ---------------------------------------------------------------------------
 // forward simulators
@@ -802,58 +807,106 @@ static int hip_fail(char *err, hipError_t e, const char *what)
     return EPI_ERR_HIP;
 }
 
-struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, innov, total; };
+struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, innov, hand_s, hand_p, hand_i, total; };
 static int lane_block_of(const epi_batch_desc *d) { return (d->lane_block <= 0 || d->lane_block >= d->B) ? d->B : d->lane_block; }
 static size_t padded_chains(const epi_batch_desc *d)
 {
     const int blk = lane_block_of(d);
     return (size_t)((d->B + blk - 1) / blk) * blk;
 }
+
+// ---------------------------------------------------------------------------
+// per-device state (the only state the library keeps besides the host entry points' context pool; both are freed by
+// epi_host_pool_release): the SIMD count of each device, and idle helper streams
+// ---------------------------------------------------------------------------
+constexpr int kMaxDevices = 64;
+constexpr int kHelperEvents = 12;
+// A helper stream of the LOWEST priority (its workgroups are placed after the caller's stream's) with the events one call
+// needs to fork work onto it and join it back.  A call leases one for the time it takes to ENQUEUE its kernels; work of
+// consecutive lessees simply queues up on the stream.
+struct Helper { hipStream_t stream = nullptr; hipEvent_t ev[kHelperEvents] = {}; };
+static std::mutex g_dev_mu;
+static std::atomic<int> g_simds[kMaxDevices];
+static std::vector<Helper *> g_helpers[kMaxDevices];
+
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+static int simd_count(int dev)
+{
+    const int v = g_simds[dev].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        return 1024;                       // MI355X; not cached, so a later call asks the runtime again
+    }
+    g_simds[dev].store(cus * 4, std::memory_order_relaxed);
+    return cus * 4;
+}
+static void helper_destroy(Helper *h)
+{
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (auto &ev : h->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete h;
+}
+static hipError_t helper_acquire(int dev, Helper **out)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        if (!g_helpers[dev].empty()) { *out = g_helpers[dev].back(); g_helpers[dev].pop_back(); return hipSuccess; }
+    }
+    Helper *h = new Helper();
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = numerically largest = lowest priority
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, lo);
+    for (auto &ev : h->ev)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e != hipSuccess) { helper_destroy(h); return e; }
+    *out = h;
+    return hipSuccess;
+}
+struct HelperLease {       // returns the helper to its device's idle list when the enqueueing call ends
+    int dev; Helper *h = nullptr;
+    explicit HelperLease(int d) : dev(d) {}
+    ~HelperLease() { if (h) { std::lock_guard<std::mutex> lk(g_dev_mu); g_helpers[dev].push_back(h); } }
+};
+static void helpers_release_all()
+{
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (int dev = 0; dev < kMaxDevices; dev++) {
+        std::vector<Helper *> mine;
+        { std::lock_guard<std::mutex> lk(g_dev_mu); mine.swap(g_helpers[dev]); }
+        if (mine.empty()) continue;
+        (void)hipSetDevice(dev);
+        for (Helper *h : mine) helper_destroy(h);
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+}
+
 // The innovation monitor leaves the forward kernels (ekf_monitor, ekf_quad.hpp) when R_v is a per-day series -- then rho
 // feeds nothing back -- and two double-written L-sample windows per lane fit the default dynamic-LDS limit.
 static bool monitor_hoisted(const epi_batch_desc *d)
 {
     return MODEL_TABLE[d->model].generic && d->r_mode == 1 && d->q_mode == 0 && d->path_hint != 2 &&
-           (size_t)4 * d->L * kWave * sizeof(double) <= 64u * 1024u && !getenv("EPIEKF_MON_INLINE");
+           (size_t)4 * d->L * kWave * sizeof(double) <= 64u * 1024u;
 }
 // Which lane mapping runs the 6-state generic models (epi_batch_desc.shape).  Auto: four lanes per chain while every
 // quad wavefront (16 chains) still gets a SIMD of its own, i.e. up to 16 384 chains on MI355X -- there the chains'
-// per-day latency is what counts and the quad kernels' instruction stream is half as long (9 375 chains: 3.9 instead of
+// per-day latency is what counts and the quad kernels' instruction stream is half as long (9 375 chains: 3.5 instead of
 // 6.1 ms per pass); beyond that the quad waves (one per SIMD at ~290 registers) would run in rounds and one lane per
-// chain, the shape with the least total work, wins (18 750 chains: 7.1 against 9.0 ms).  profiles/r02/batch_size_sweep.txt.
-// EPIEKF_SHAPE=1|2 overrides (measurement).
-static int g_simd_count = 0;
-static int simd_count()
-{
-    if (!g_simd_count) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        g_simd_count = cus * 4;
-    }
-    return g_simd_count;
-}
-// returns EPI_SHAPE_LANE, _QUAD or _PAIR.  pair_ok: the pair kernels have no inline monitor (R_v must be a per-day series)
-static int pick_shape(int shape, int m, bool generic, int B, bool pair_ok)
-{
-    if (m != 6 || !generic) return EPI_SHAPE_LANE;
-    if (const char *env = getenv("EPIEKF_SHAPE")) { const int v = atoi(env); if (v >= 1 && v <= 3) shape = v; }
-    if (shape == EPI_SHAPE_PAIR) return pair_ok ? EPI_SHAPE_PAIR : EPI_SHAPE_LANE;
-    if (shape == EPI_SHAPE_QUAD || shape == EPI_SHAPE_LANE) return shape;
-    if (((long)B + kQC - 1) / kQC <= (long)simd_count()) return EPI_SHAPE_QUAD;   // the quad waves still get a SIMD each
-    // (two lanes per chain is never chosen here: measured between the other two everywhere -- 18 750 chains 6.3 ms against
-    // 6.1 one lane per chain, 9 375 chains 4.0 against 3.5 four lanes per chain; profiles/r02/batch_size_sweep.txt)
-    (void)pair_ok;
-    return EPI_SHAPE_LANE;
-}
-// assume_packed: sizing / layout questions asked before epi_ekf_precheck_device has set path_hint (workspace bytes,
-// preferred lane_block) answer for the case that the batch will qualify for the packed kernels
-static int shape_of(const epi_batch_desc *d, bool assume_packed = false)
+// chain, the shape with the least total work, wins (18 750 chains: 6.1 against 8.4 ms).  profiles/r02/batch_size_sweep.txt.
+static int shape_of(const epi_batch_desc *d, int dev)
 {
     const ModelInfo &mi = MODEL_TABLE[d->model];
-    if (d->storage) return EPI_SHAPE_LANE;
-    const bool packed = d->path_hint == 1 || (assume_packed && d->path_hint == 0);
-    return pick_shape(d->shape, mi.m, mi.generic != 0, d->B, monitor_hoisted(d) && packed);
+    if (mi.m != 6 || !mi.generic || d->storage) return EPI_SHAPE_LANE;
+    if (d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_LANE) return d->shape;
+    return ((long)d->B + kQC - 1) / kQC <= (long)simd_count(dev) ? EPI_SHAPE_QUAD : EPI_SHAPE_LANE;
 }
 
 static WsLayout ws_layout(const epi_batch_desc *d)
@@ -870,15 +923,17 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.s_plus = take(!(om & EPI_OUT_S_PLUS), nS);
     w.p_minus = take(!(om & EPI_OUT_P_MINUS), nP);
     w.p_plus = take(!(om & EPI_OUT_P_PLUS), nP);
-    // smoother intermediates of the generic models: X = pinv(P_MINUS) and its rank word per (step, chain)
+    // smoother intermediates of the generic models: X = pinv(P_MINUS), packed upper triangle, and its rank word per (step, chain)
     const bool generic = MODEL_TABLE[d->model].generic;
-    // X: packed upper triangle, or all m*m rows where the two-lanes-per-chain smoother may read it (whole rows per lane)
-    const bool x_full = shape_of(d, true) == EPI_SHAPE_PAIR;
-    w.x = take(generic, (size_t)d->T * (x_full ? m * m : m * (m + 1) / 2) * Bp * sizeof(double));
+    w.x = take(generic, (size_t)d->T * (m * (m + 1) / 2) * Bp * sizeof(double));
     w.rank = take(generic, (size_t)d->T * Bp * sizeof(int32_t));
     w.flag = take(generic, 256);
     // ekf_monitor reads the fp64 innovations: workspace when the caller does not take them as an fp64 output
     w.innov = take(monitor_hoisted(d) && (d->storage || !(d->out_mask & EPI_OUT_INNOVATIONS)), (size_t)d->T * Bp * sizeof(double));
+    // hand-over rows between two backward launches (epi_sweep_run_device cuts the smoother where the horizon ends)
+    w.hand_s = take(generic, (size_t)m * Bp * sizeof(double));
+    w.hand_p = take(generic, (size_t)m * m * Bp * sizeof(double));
+    w.hand_i = take(generic, Bp * sizeof(int32_t));
     w.total = off;
     return w;
 }
@@ -886,75 +941,13 @@ static WsLayout ws_layout(const epi_batch_desc *d)
 // ---------------------------------------------------------------------------
 // launch logic
 // ---------------------------------------------------------------------------
-// The sequential kernels keep one chain per lane and (for m = 6) one wave per SIMD, so a batch whose wave
-// count is not a multiple of the chip's SIMD count leaves a tail round in which few SIMDs work, and while a
-// sequential kernel is latency-bound the rest of the chip idles.  A full call (phase 0) may therefore be split
-// into chunks of chains, each enqueued (forward -> pinv -> backward) on its own helper stream: the hardware
-// queues then interleave one chunk's (chain, step)-parallel eks_pinv grid with the other chunks' long-lived
-// sequential waves.  Chunks never share data, so stream order inside a chunk is the only dependency.
-constexpr int kMaxChunks = 16;
-struct SideStreams {
-    hipStream_t stream[kMaxChunks] = {};
-    hipEvent_t join[kMaxChunks] = {};
-    hipEvent_t fork = nullptr;
-    int n = 0, device = -1;
-};
-static thread_local SideStreams g_side;   // helper streams of the calling thread (created on first use)
-
-// a helper stream of the LOWEST priority: its eks_pinv workgroups are placed after the forward kernel's (pipelined launch)
-struct LowPrioStream { hipStream_t stream = nullptr; hipEvent_t ev[10] = {}; int device = -1; };
-static thread_local LowPrioStream g_low;
-static hipError_t low_prio_stream(LowPrioStream **out)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (g_low.device != dev) { g_low = LowPrioStream(); g_low.device = dev; }
-    if (!g_low.stream) {
-        int lo = 0, hi = 0;
-        if ((e = hipDeviceGetStreamPriorityRange(&lo, &hi)) != hipSuccess) return e;   // lo = numerically largest = lowest
-        if ((e = hipStreamCreateWithPriority(&g_low.stream, hipStreamNonBlocking, lo)) != hipSuccess) return e;
-        for (auto &ev : g_low.ev)
-            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
-    }
-    *out = &g_low;
-    return hipSuccess;
-}
-
-static hipError_t side_streams(int n, SideStreams **out)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (g_side.device != dev) { g_side = SideStreams(); g_side.device = dev; }
-    if (!g_side.fork && (e = hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming)) != hipSuccess) return e;
-    for (; g_side.n < n; g_side.n++) {
-        if ((e = hipStreamCreateWithFlags(&g_side.stream[g_side.n], hipStreamNonBlocking)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&g_side.join[g_side.n], hipEventDisableTiming)) != hipSuccess) return e;
-    }
-    *out = &g_side;
-    return hipSuccess;
-}
-
 // Lanes per wave for the one-chain-per-lane kernels.  `waves_per_simd` waves of such a kernel fit a SIMD (1 for the
 // 6-state kernels, 2 for the 3-state ones).  If cn/64 waves exceed what is resident at once, the launch would run
 // in rounds and the last round would leave most SIMDs idle while its few waves are limited by what ONE compute unit
 // can pull from memory; narrower waves, a multiple of 8 lanes (64-byte segments), make every round equally full.
-// EPIEKF_LANES=n overrides (measurement).
-static int balanced_lanes(int cn, int waves_per_simd)
+static int balanced_lanes(int cn, int waves_per_simd, int dev)
 {
-    static int simds = 0;
-    if (!simds) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        simds = cus * 4;
-    }
-    if (const char *env = getenv("EPIEKF_LANES")) {
-        const int v = atoi(env);
-        if (v >= 1 && v <= kWave) return v;
-    }
-    const long cap = (long)simds * waves_per_simd;
+    const long cap = (long)simd_count(dev) * waves_per_simd;
     const long w64 = (cn + kWave - 1) / kWave;
     if (w64 <= cap) return kWave;
     const long rounds = (w64 + cap - 1) / cap;
@@ -963,18 +956,31 @@ static int balanced_lanes(int cn, int waves_per_simd)
     return (int)(lw > kWave ? kWave : lw);
 }
 
-// the innovation monitor of a chain range as its own launch (after the forward kernel that wrote the innovations)
+// the scoring tail of the Pareto sweep (epi_sweep_run_device): device pointers, validated by the entry point
+struct Tail {
+    int t_hist, R, P;
+    const double *sp, *J0_prefix, *J1_prefix;
+    double *J0, *J1;
+    int32_t *on_front, *i_opt;
+};
+// what one call enqueues
+struct Launch {
+    int dev, phase, hint, time_pipe;
+    bool smooth;
+    const Tail *tail;
+};
+
+// the innovation monitor as its own launch (after the forward kernel that wrote the innovations)
 template <int FLIP>
-static hipError_t launch_monitor(const KArgs &ka, int cn, hipStream_t st)
+static hipError_t launch_monitor(const KArgs &ka, int dev, hipStream_t st)
 {
     if (!ka.mon_hoist || !(ka.rho || ka.f.rho)) return hipSuccess;
-    if (ka.mon_defer) return hipSuccess;
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
-    const int mb = (cn + kWave - 1) / kWave;
+    const int mb = (ka.B + kWave - 1) / kWave;
     // time segments (each pays a 2L-2-step warm-up): enough of them that the grid gives every SIMD about eight of these
     // light waves (a lane's 100-step scan is latency-bound: 0.70 ms with two segments, 0.25 ms with eight at 75 000 chains),
     // none shorter than ~64 steps
-    int nseg = (8 * simd_count() + mb - 1) / mb;
+    int nseg = (8 * simd_count(dev) + mb - 1) / mb;
     const int max_seg = ka.T / 64 > 1 ? ka.T / 64 : 1;
     nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
     if (ka.L == 21) hipLaunchKernelGGL((ekf_monitor<FLIP, 21>), dim3(mb, nseg), dim3(kWave), shm, st, ka, ka.dense_flag);
@@ -982,47 +988,32 @@ static hipError_t launch_monitor(const KArgs &ka, int cn, hipStream_t st)
     return hipGetLastError();
 }
 
-// phase: 0 = everything; 1 = forward kernel; 2 = smoother (pinv + backward); 3 = pinv kernel; 4 = backward kernel
+// forward kernel(s) over filter steps [ka.k_begin, ka.k_end) of all chains
 template <int M, int FLIP, int GENERIC>
-static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth, int hint, size_t shmem, hipStream_t st)
+static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
 {
-    ka.c0 = c0; ka.cn = cn;
-    ka.lw = balanced_lanes(cn, M == 6 ? 1 : 2);
-    const int blocks = (cn + ka.lw - 1) / ka.lw;
-    const bool run_sym = GENERIC && hint != 2, run_dense = !GENERIC || hint != 1;
+    ka.c0 = 0; ka.cn = ka.B;
+    ka.lw = balanced_lanes(ka.B, M == 6 ? 1 : 2, L.dev);
+    const int blocks = (ka.B + ka.lw - 1) / ka.lw;
+    const size_t shmem = (size_t)3 * ka.L * kWave * sizeof(double);
+    // hint 0: both variants are enqueued, the one ekf_precheck did not select returns at once
+    const bool run_sym = GENERIC && L.hint != 2, run_dense = !GENERIC || L.hint != 1;
     hipError_t e = hipSuccess;
-    if constexpr (M == 6 && GENERIC) {
-        if (ka.pair && run_sym) {
-            // two lanes per chain: 32 chains per wavefront (ekf_pair.hpp); chosen only with path_hint = 1 and a hoisted monitor
-            const int pblocks = (cn + kPC - 1) / kPC;
-            const bool fast = ka.blk == kPC;
-            if (phase == 0 || phase == 1) {
-                if (fast) hipLaunchKernelGGL((ekf_fwd_pair<FLIP, kPC>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-                else hipLaunchKernelGGL((ekf_fwd_pair<FLIP, 0>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-                if ((e = launch_monitor<FLIP>(ka, cn, st)) != hipSuccess) return e;
-            }
-            if (!smooth) return e;
-            if (ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
-                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, st, ka);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-            }
-            if (phase == 0 || phase == 2 || phase == 4) {
-                if (fast) hipLaunchKernelGGL((eks_bwd_pair<FLIP, kPC>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-                else hipLaunchKernelGGL((eks_bwd_pair<FLIP, 0>), dim3(pblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-                e = hipGetLastError();
-            }
-            return e;
-        }
-        if (ka.quad && run_sym) {
-            // four lanes per chain: 16 chains per wavefront (ekf_quad.hpp); the dense fall-back keeps its own mapping
-            const int qblocks = (cn + kQC - 1) / kQC;
-            if (phase == 0 || phase == 1) {
-                // the specialisation for the layout and the window length this shape is meant for, or the general one
+    if (run_sym) {
+        bool done = false;
+        if constexpr (M == 6 && GENERIC) {
+            if (ka.quad) {
+                // four lanes per chain, 16 chains per wavefront (ekf_quad.hpp): the specialisation for the layout and the
+                // window length this shape is meant for, or the general one
+                const int qblocks = (ka.B + kQC - 1) / kQC;
                 const size_t qshm = ((size_t)(ka.mon_hoist ? 0 : 6 * ka.L) + kNpi) * kQC * sizeof(double);
                 const bool fast = ka.blk == kQC && ka.L == 21;
-                const bool solo = qblocks <= simd_count();       // every wave can have a SIMD of its own: keep it that way
+                const bool solo = qblocks <= simd_count(L.dev);   // every wave can have a SIMD of its own: keep it that way
                 auto go = [&](auto kern) -> hipError_t {
+                    if (qshm > 64u * 1024u) {      // inline monitor with a long window: above the default dynamic-LDS limit
+                        const hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qshm);
+                        if (ea != hipSuccess) return ea;
+                    }
                     hipLaunchKernelGGL(kern, dim3(qblocks), dim3(kWave), qshm, st, ka, ka.dense_flag);
                     return hipGetLastError();
                 };
@@ -1033,74 +1024,108 @@ static hipError_t enqueue_chunk(KArgs ka, int c0, int cn, int phase, bool smooth
                     e = fast ? go(ekf_fwd_quad<FLIP, kQC, 21, 1, 0>) : go(ekf_fwd_quad<FLIP, 0, 0, 1, 0>);
                 }
                 if (e != hipSuccess) return e;
-                if ((e = launch_monitor<FLIP>(ka, cn, st)) != hipSuccess) return e;
-                if (run_dense) {
-                    hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
-                    if ((e = hipGetLastError()) != hipSuccess) return e;
-                }
+                done = true;
             }
-            if (!smooth) return e;
-            if (ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
-                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, st, ka);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-            }
-            if (phase == 0 || phase == 2 || phase == 4) {
-                if (ka.blk == kQC) hipLaunchKernelGGL((eks_bwd_quad<FLIP, kQC>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-                else hipLaunchKernelGGL((eks_bwd_quad<FLIP, 0>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-                if (run_dense) {
-                    hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
-                    e = hipGetLastError();
-                }
-            }
-            return e;
         }
-    }
-    if (phase == 0 || phase == 1) {
-        if (run_sym) {   // hint 0: both variants are enqueued, the one ekf_precheck did not select returns at once
+        if (!done) {
             // narrow (balanced) waves: the variant with LDS-resident model constants and LDS sized by 40 lanes -- 298
             // instead of 408 VGPRs (a third of the AGPR traffic), still four workgroups per CU
             const size_t per_lane = ((size_t)3 * ka.L + 4 * kNpi) * sizeof(double);
-            const bool lp = M == 6 && ka.lw <= kPipeLanes && per_lane * kPipeLanes * 4 <= 160u * 1024u && !getenv("EPIEKF_NO_LP");
+            const bool lp = M == 6 && ka.lw <= kPipeLanes && per_lane * kPipeLanes * 4 <= 160u * 1024u;
             if (ka.mon_hoist) {         // no windows in LDS: only the LP variant's model vectors
                 const size_t lp_shm = (size_t)4 * kNpi * kPipeLanes * sizeof(double);
                 if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1, 0>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                 else if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1, 0, 0>), dim3(blocks), dim3(kWave), lp_shm, st, ka, ka.dense_flag);
                 else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 0, 0>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
             } else if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
-            else if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), per_lane * kPipeLanes, st, ka, ka.dense_flag);
-            else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            if ((e = launch_monitor<FLIP>(ka, cn, st)) != hipSuccess) return e;
-        }
-        if (run_dense) {
-            hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
+            else if (lp) {
+                const size_t shm = per_lane * kPipeLanes;
+                if (shm > 64u * 1024u &&
+                    (e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess)
+                    return e;
+                hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), shm, st, ka, ka.dense_flag);
+            } else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
     }
-    if (!smooth) return e;
-    if (GENERIC && ka.T > 1 && (phase == 0 || phase == 2 || phase == 3)) {
-        hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, st, ka);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    if (phase == 0 || phase == 2 || phase == 4) {
-        if (run_sym) {
-            if (ka.stor) hipLaunchKernelGGL((eks_bwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-            else hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (run_dense) {
-            hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
-            e = hipGetLastError();
-        }
+    if (run_dense) {
+        hipLaunchKernelGGL((ekf_fwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), shmem, st, ka);
+        e = hipGetLastError();
     }
     return e;
 }
 
+// X = pinv(P(j|j-1)) for the `nsteps` array positions from pinv_pos0 + step0 on, all chains
+template <int M>
+static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st)
+{
+    if (nsteps <= 0) return hipSuccess;
+    ka.c0 = 0; ka.cn = ka.B; ka.pinv_step0 = step0;
+    hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
+    return hipGetLastError();
+}
+
+// backward recursion over smoother steps ka.bk_from ... ka.bk_to (the dense kernels only know the full range)
 template <int M, int FLIP, int GENERIC>
-static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint, int chunks, hipStream_t st)
+static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
+{
+    ka.c0 = 0; ka.cn = ka.B;
+    ka.lw = balanced_lanes(ka.B, M == 6 ? 1 : 2, L.dev);
+    const int blocks = (ka.B + ka.lw - 1) / ka.lw;
+    const bool run_sym = GENERIC && L.hint != 2, run_dense = !GENERIC || L.hint != 1;
+    hipError_t e = hipSuccess;
+    if (run_sym) {
+        bool done = false;
+        if constexpr (M == 6 && GENERIC) {
+            if (ka.quad) {
+                const int qblocks = (ka.B + kQC - 1) / kQC;
+                if (ka.blk == kQC) hipLaunchKernelGGL((eks_bwd_quad<FLIP, kQC>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((eks_bwd_quad<FLIP, 0>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                done = true;
+            }
+        }
+        if (!done) {
+            if (ka.stor) hipLaunchKernelGGL((eks_bwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+            else hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (run_dense) {
+        hipLaunchKernelGGL((eks_bwd<M, FLIP, GENERIC>), dim3(blocks), dim3(kWave), 0, st, ka);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+// scoring of the sweep's horizon (TrainPredictPrescribeNPI.m:481-493) from the u_opt_smooth the smoother just wrote,
+// then the Pareto filter and optimum per region (:624-633) when the call holds whole regions
+static hipError_t enqueue_tail(const KArgs &ka, const Tail &t, hipStream_t st)
+{
+    epi_sim_desc sd{};
+    sd.abi_version = EPIEKF_ABI_VERSION; sd.B = ka.B; sd.K = ka.T - t.t_hist; sd.Su = ka.B; sd.n_npi = ka.n_npi;
+    sd.noise = 0; sd.with_cost = 1; sd.prefix_days = t.t_hist; sd.u_block = ka.blk >= ka.B ? 0 : ka.blk;
+    // day t_hist of u_opt_smooth: a time slice is n_npi rows of nblk * blk chains in either layout
+    const double *u_h = ka.u_opt_smooth + (size_t)t.t_hist * ka.n_npi * ((size_t)ka.nblk * ka.blk);
+    hipLaunchKernelGGL(sialpha_sim, dim3((ka.B + 255) / 256), dim3(256), 0, st, sd, (const int32_t *)nullptr, u_h, t.sp,
+                       (const double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, t.J0, t.J1,
+                       t.J0_prefix, t.J1_prefix);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || (!t.on_front && !t.i_opt)) return e;
+    hipLaunchKernelGGL(pareto_front, dim3(t.R), dim3(256), (size_t)2 * t.P * sizeof(double), st, t.P, t.J0, t.J1, t.on_front, t.i_opt);
+    return hipGetLastError();
+}
+
+// Forward pass in time segments (percent of T where each ends).  pinv(P(k|k-1)) needs nothing but the forward pass's
+// output of day k and the smoother consumes X in REVERSE time order, so only the pinv grid of the last segment stands
+// between the end of the forward pass and the start of the smoother: the last segments are short.
+constexpr int kTimeCuts[] = {0, 40, 70, 90, 98, 100};
+constexpr int kTimeSeg = (int)(sizeof(kTimeCuts) / sizeof(kTimeCuts[0])) - 1;
+
+template <int M, int FLIP, int GENERIC>
+static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
 {
     const size_t shmem = (size_t)3 * ka.L * kWave * sizeof(double);
+    const int T = ka.T, phase = L.phase;
     hipError_t e = hipSuccess;
     if (phase == 0 || phase == 1) {
         if (shmem > 64u * 1024u) {   // above the default dynamic-LDS limit
@@ -1120,147 +1145,95 @@ static hipError_t launch_chain(const KArgs &ka, int phase, bool smooth, int hint
             // hint 0: fast path unless ekf_precheck finds a non-symmetric Ps_init / non-diagonal Q_w in the batch;
             // hint 1 / 2: the caller decided; the flag the kernels test is set accordingly
             if ((e = hipMemsetAsync(ka.dense_flag, 0, sizeof(int), st)) != hipSuccess) return e;
-            if (hint == 0) {
+            if (L.hint == 0) {
                 hipLaunchKernelGGL((ekf_precheck<M>), dim3((ka.B + 255) / 256), dim3(256), 0, st, ka, ka.dense_flag, 0);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
-            } else if (hint == 2) {
+            } else if (L.hint == 2) {
                 hipLaunchKernelGGL((ekf_precheck<M>), dim3(1), dim3(64), 0, st, ka, ka.dense_flag, 1);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             }
         }
     }
-    if (phase == 0 && chunks == -1 && smooth) {
-        // "round + tail" split: the main chunk is a whole number of rounds of one wave per SIMD; the tail chunk's
-        // forward kernel starts when the main chunk's forward kernel has finished (so that it does not take
-        // SIMDs from it) and then runs beside the main chunk's eks_pinv grid
-        int dev = 0, cus = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        const int simds = cus * 4, waves = (ka.B + kWave - 1) / kWave;
-        const int main_chains = (waves / simds) * simds * kWave, tail_chains = ka.B - main_chains;
-        if (main_chains > 0 && tail_chains > 0) {
-            SideStreams *ss = nullptr;
-            if ((e = side_streams(1, &ss)) != hipSuccess) return e;
-            if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, 0, main_chains, 1, smooth, hint, shmem, st)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ss->fork, st)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(ss->stream[0], ss->fork, 0)) != hipSuccess) return e;
-            if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, main_chains, tail_chains, 0, smooth, hint, shmem, ss->stream[0])) != hipSuccess) return e;
-            if ((e = hipEventRecord(ss->join[0], ss->stream[0])) != hipSuccess) return e;
-            if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, 0, main_chains, 2, smooth, hint, shmem, st)) != hipSuccess) return e;
-            return hipStreamWaitEvent(st, ss->join[0], 0);
+    // smoother positions of filter steps 2..T (array positions 1..T-1, or 0..T-2 for the time-flipped models)
+    const bool overlap = GENERIC && phase == 0 && L.smooth && L.hint == 1;
+    if (!overlap) {
+        // one stage after the other on the caller's stream (single stages for per-kernel timing, the forward pass alone,
+        // batches that may take the dense kernels, the NewCase models)
+        if (phase == 0 || phase == 1) {
+            if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
+            if (GENERIC && L.hint != 2 && (e = launch_monitor<FLIP>(ka, L.dev, st)) != hipSuccess) return e;
         }
-        return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
-    }
-    if (GENERIC && phase == 0 && (chunks == 0 || chunks == 1 || chunks == -3) && smooth && hint == 1 && ka.mon_hoist && !ka.stor &&
-        ka.T >= 128 && !getenv("EPIEKF_NO_TIME_PIPE")) {
-        // Pipelined in TIME.  A batch that does not fill the chip (the shards of the sweep on 2, 4, 8 GPUs) leaves SIMDs idle
-        // while its sequential forward waves crawl through the T days, and pinv(P(k|k-1)) needs nothing but the forward
-        // pass's output of day k: the forward kernel runs in kTimeSeg launches of T / kTimeSeg days each (a later segment
-        // resumes from the S_MINUS / P_MINUS the previous one stored: same bits), and after each of them the eks_pinv grid
-        // of ITS days starts on a second stream, beside the next forward segment.  Only the last segment's pinv is left
-        // when the forward pass ends.  Not for a batch that fills the chip (nothing idles: measured level, round 1).
-        const long fwd_waves = ka.quad ? ((long)ka.B + kQC - 1) / kQC : ka.pair ? ((long)ka.B + kPC - 1) / kPC : ((long)ka.B + kWave - 1) / kWave;
-        if (chunks == -3 || fwd_waves * 4 <= (long)simd_count() * 3) {
-            constexpr int kTimeSeg = 4;
-            LowPrioStream *lp = nullptr;
-            if ((e = low_prio_stream(&lp)) != hipSuccess) return e;
-            const int T = ka.T;
-            for (int sg = 0; sg < kTimeSeg; sg++) {
-                KArgs kc = ka;
-                kc.k_begin = (int)((long)T * sg / kTimeSeg);
-                kc.k_end = (sg == kTimeSeg - 1) ? T : (int)((long)T * (sg + 1) / kTimeSeg);
-                // (the monitor kernel follows after the loop, beside the last segment's pinv grid, not in front of it)
-                kc.mon_defer = 1;
-                if ((e = enqueue_chunk<M, FLIP, GENERIC>(kc, 0, ka.B, 1, smooth, hint, shmem, st)) != hipSuccess) return e;
-                if ((e = hipEventRecord(lp->ev[sg], st)) != hipSuccess) return e;
-                if ((e = hipStreamWaitEvent(lp->stream, lp->ev[sg], 0)) != hipSuccess) return e;
-                // filter steps whose P(j|j-1) exists now and has not been inverted yet: j_lo .. j_hi (the smoother needs
-                // j = 1 .. T-1); array position of step j: j, or T-1-j for the time-flipped models
-                const int j_lo = kc.k_begin + 1, j_hi = (kc.k_end < T) ? kc.k_end : T - 1;
-                if (j_hi >= j_lo) {
-                    KArgs kp = ka;
-                    kp.c0 = 0; kp.cn = ka.B;
-                    kp.pinv_step0 = FLIP ? (T - 1 - j_hi) : (j_lo - 1);
-                    hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(j_hi - j_lo + 1)),
-                                       dim3(pinv_wg<M>()), 0, lp->stream, kp);
-                    if ((e = hipGetLastError()) != hipSuccess) return e;
-                }
-            }
-            { KArgs km = ka; km.c0 = 0; km.cn = ka.B; if ((e = launch_monitor<FLIP>(km, ka.B, st)) != hipSuccess) return e; }
-            if ((e = hipEventRecord(lp->ev[kTimeSeg], lp->stream)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(st, lp->ev[kTimeSeg], 0)) != hipSuccess) return e;
-            return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, 4, smooth, hint, shmem, st);
+        if (!L.smooth) return e;
+        if (GENERIC && (phase == 0 || phase == 2 || phase == 3) && (e = enqueue_pinv<M>(ka, 0, T - 1, st)) != hipSuccess) return e;
+        if (phase == 0 || phase == 2 || phase == 4) {
+            if ((e = enqueue_bwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         }
+        if (phase == 0 && L.tail) e = enqueue_tail(ka, *L.tail, st);
+        return e;
     }
-    if (GENERIC && phase == 0 && chunks == -2 && smooth && hint == 1 && ka.T > 1 && !ka.quad && !ka.stor) {
-        // Pipelined halves.  The forward kernel of the second half and the eks_pinv grid of the first half are in flight
-        // together, and -- because this forward variant (LDS-resident model constants, LDS sized by the lanes used)
-        // needs 298 VGPRs and eks_pinv 168 -- they share SIMDs: the VALU-bound Jacobi runs in the issue slots the
-        // latency-bound filter waves leave idle.  The backward kernel (492 VGPRs) cannot share; it follows as one launch.
-        int dev = 0, cus = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        const size_t per_lane = ((size_t)3 * ka.L + 4 * kNpi) * sizeof(double);
-        const int lw = kPipeLanes;
-        const bool lds_ok = per_lane * lw * 4 <= 160u * 1024u;         // four forward workgroups per CU by LDS (L <= 26)
-        const int half = (ka.B / 2 + 7) / 8 * 8;
-        if (lds_ok && half > 0 && half < ka.B) {
-            LowPrioStream *lp = nullptr;
-            if ((e = low_prio_stream(&lp)) != hipSuccess) return e;
-            const size_t shm = per_lane * lw;
-            if (shm > 64u * 1024u &&
-                (e = hipFuncSetAttribute((const void *)ekf_fwd_sym<M, FLIP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)) != hipSuccess)
-                return e;
-            const int c0s[2] = {0, half}, cns[2] = {half, ka.B - half};
-            for (int h = 0; h < 2; h++) {
-                KArgs kc = ka;
-                kc.c0 = c0s[h]; kc.cn = cns[h]; kc.lw = lw;
-                hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1>), dim3((kc.cn + lw - 1) / lw), dim3(kWave), shm, st, kc, kc.dense_flag);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-                if ((e = hipEventRecord(lp->ev[h], st)) != hipSuccess) return e;
-                if ((e = hipStreamWaitEvent(lp->stream, lp->ev[h], 0)) != hipSuccess) return e;
-                hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((kc.cn + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)(ka.T - 1)), dim3(pinv_wg<M>()), 0, lp->stream, kc);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-            }
-            if ((e = hipEventRecord(lp->ev[2], lp->stream)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(st, lp->ev[2], 0)) != hipSuccess) return e;
-            return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, 4, smooth, hint, shmem, st);
+
+    // A full call on the packed kernels.  What does not lie on the critical path runs on a helper stream:
+    //   * the innovation monitor (needs the forward pass only) beside the pinv grid and the smoother;
+    //   * pipelined in TIME: a batch that does not fill the chip (the shards of the sweep on 2, 4, 8 GPUs) leaves SIMDs idle
+    //     while its sequential forward waves crawl through the T days.  The forward kernel then runs in kTimeSeg launches (a
+    //     later segment resumes from the S_MINUS / P_MINUS the previous one stored: same bits), and after each of them the
+    //     eks_pinv grid of ITS days starts on the helper stream, beside the next forward segment.  Not for a batch that
+    //     fills the chip (nothing idles: measured level, round 1);
+    //   * the sweep's scoring tail: the horizon's u_opt_smooth is final after the smoother's first T - 1 - t_hist steps,
+    //     so the recursion is cut there and scoring + Pareto filter run beside the rest of it.
+    HelperLease lease(L.dev);
+    if ((e = helper_acquire(L.dev, &lease.h)) != hipSuccess) return e;
+    Helper *h = lease.h;
+    int ne = 0;
+    auto fork = [&](hipStream_t from, hipStream_t to) -> hipError_t {     // `to` continues after what `from` holds now
+        hipError_t ee = hipEventRecord(h->ev[ne], from);
+        if (ee == hipSuccess) ee = hipStreamWaitEvent(to, h->ev[ne], 0);
+        ne++;
+        return ee;
+    };
+    const long fwd_waves = ka.quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
+    const bool tp = ka.mon_hoist && !ka.stor && T >= 128 && L.time_pipe >= 0 &&
+                    (L.time_pipe == 1 || fwd_waves * 4 <= (long)simd_count(L.dev) * 3);
+    bool helper_busy = false;
+    if (tp) {
+        for (int sg = 0; sg < kTimeSeg; sg++) {
+            KArgs kc = ka;
+            kc.k_begin = (int)((long)T * kTimeCuts[sg] / 100);
+            kc.k_end = (sg == kTimeSeg - 1) ? T : (int)((long)T * kTimeCuts[sg + 1] / 100);
+            if (kc.k_end <= kc.k_begin) continue;
+            if ((e = enqueue_fwd<M, FLIP, GENERIC>(kc, L, st)) != hipSuccess) return e;
+            if ((e = fork(st, h->stream)) != hipSuccess) return e;
+            // filter steps whose P(j|j-1) exists now and has not been inverted yet: j_lo .. j_hi (the smoother needs
+            // j = 1 .. T-1); array position of step j: j, or T-1-j for the time-flipped models
+            const int j_lo = kc.k_begin + 1, j_hi = (kc.k_end < T) ? kc.k_end : T - 1;
+            if ((e = enqueue_pinv<M>(ka, FLIP ? (T - 1 - j_hi) : (j_lo - 1), j_hi - j_lo + 1, h->stream)) != hipSuccess) return e;
         }
+        if ((e = fork(h->stream, st)) != hipSuccess) return e;       // the smoother needs every pinv grid
+        helper_busy = true;
+    } else {
+        if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
+        if (ka.mon_hoist && (ka.rho || ka.f.rho) && (e = fork(st, h->stream)) != hipSuccess) return e;
+        if ((e = enqueue_pinv<M>(ka, 0, T - 1, st)) != hipSuccess) return e;
     }
-    if (GENERIC && phase == 0 && chunks <= 1 && smooth && hint == 1 && ka.mon_hoist && (ka.rho || ka.f.rho)) {
-        // a full call on one stream: the monitor kernel needs the forward pass only, so it runs on the helper stream beside the
-        // pinv grid and the smoother instead of in front of them
-        LowPrioStream *lp = nullptr;
-        if ((e = low_prio_stream(&lp)) != hipSuccess) return e;
-        KArgs kc = ka;
-        kc.mon_defer = 1;
-        if ((e = enqueue_chunk<M, FLIP, GENERIC>(kc, 0, ka.B, 1, smooth, hint, shmem, st)) != hipSuccess) return e;
-        if ((e = hipEventRecord(lp->ev[0], st)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(lp->stream, lp->ev[0], 0)) != hipSuccess) return e;
-        { KArgs km = ka; km.c0 = 0; km.cn = ka.B; if ((e = launch_monitor<FLIP>(km, ka.B, lp->stream)) != hipSuccess) return e; }
-        if ((e = hipEventRecord(lp->ev[1], lp->stream)) != hipSuccess) return e;
-        if ((e = enqueue_chunk<M, FLIP, GENERIC>(kc, 0, ka.B, 2, smooth, hint, shmem, st)) != hipSuccess) return e;
-        return hipStreamWaitEvent(st, lp->ev[1], 0);
+    if (ka.mon_hoist && (ka.rho || ka.f.rho)) {
+        if ((e = launch_monitor<FLIP>(ka, L.dev, h->stream)) != hipSuccess) return e;
+        helper_busy = true;
     }
-    if (phase != 0 || chunks <= 1 || ka.B < chunks * kWave)
-        return enqueue_chunk<M, FLIP, GENERIC>(ka, 0, ka.B, phase, smooth, hint, shmem, st);
-    // chunked: fork the helper streams off the caller's stream, one chunk each, join back
-    SideStreams *ss = nullptr;
-    if ((e = side_streams(chunks, &ss)) != hipSuccess) return e;
-    if ((e = hipEventRecord(ss->fork, st)) != hipSuccess) return e;
-    const int waves = (ka.B + kWave - 1) / kWave;
-    int c0 = 0;
-    for (int i = 0; i < chunks; i++) {
-        const int w = waves / chunks + (i < waves % chunks ? 1 : 0);      // whole waves per chunk
-        const int cn = (i == chunks - 1) ? ka.B - c0 : w * kWave;
-        if (cn <= 0) continue;
-        if ((e = hipStreamWaitEvent(ss->stream[i], ss->fork, 0)) != hipSuccess) return e;
-        if ((e = enqueue_chunk<M, FLIP, GENERIC>(ka, c0, cn, 0, smooth, hint, shmem, ss->stream[i])) != hipSuccess) return e;
-        if ((e = hipEventRecord(ss->join[i], ss->stream[i])) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(st, ss->join[i], 0)) != hipSuccess) return e;
-        c0 += cn;
+    if (L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2) {
+        KArgs kb = ka;
+        kb.bk_from = T - 2; kb.bk_to = L.tail->t_hist;              // the horizon days
+        if ((e = enqueue_bwd<M, FLIP, GENERIC>(kb, L, st)) != hipSuccess) return e;
+        if ((e = fork(st, h->stream)) != hipSuccess) return e;
+        if ((e = enqueue_tail(ka, *L.tail, h->stream)) != hipSuccess) return e;
+        helper_busy = true;
+        kb.bk_from = L.tail->t_hist - 1; kb.bk_to = 0;              // the observed days
+        if ((e = enqueue_bwd<M, FLIP, GENERIC>(kb, L, st)) != hipSuccess) return e;
+    } else {
+        if ((e = enqueue_bwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
+        if (L.tail && (e = enqueue_tail(ka, *L.tail, st)) != hipSuccess) return e;
     }
-    return hipSuccess;
+    if (helper_busy) e = fork(h->stream, st);
+    return e;
 }
 
 }  // namespace epi
@@ -1314,9 +1287,9 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     // three fp64 windows of L samples per lane must fit the CU's 160 KiB LDS
     if (d->phase < 0 || d->phase > 4) { set_err(err, "phase must be 0..4"); return EPI_ERR_BAD_ARG; }
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
-    if (d->chunks < -3) { set_err(err, "chunks must be >= -3"); return EPI_ERR_BAD_ARG; }
+    if (d->time_pipe < -1 || d->time_pipe > 1) { set_err(err, "time_pipe must be -1 (off), 0 (auto) or 1 (on)"); return EPI_ERR_BAD_ARG; }
     if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
-    if (d->shape < 0 || d->shape > 3) { set_err(err, "shape must be 0 (auto), 1 (lane), 2 (quad) or 3 (pair per chain)"); return EPI_ERR_BAD_ARG; }
+    if (d->shape < 0 || d->shape > 2) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain) or 2 (four lanes per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
@@ -1336,13 +1309,13 @@ int epi_ekf_preferred_lane_block(const epi_batch_desc *d)
     probe = *d; probe.lane_block = 0;
     if (epi_ekf_validate(&probe, nullptr) != EPI_OK) return 0;
     const ModelInfo &mi = MODEL_TABLE[d->model];
-    const int shp = shape_of(d, true);
-    const int lw = shp == EPI_SHAPE_QUAD ? kQC : shp == EPI_SHAPE_PAIR ? kPC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2);
+    const int dev = current_device();
+    const int lw = shape_of(d, dev) == EPI_SHAPE_QUAD ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2, dev);
     return lw < d->B ? lw : d->B;
 }
 
-int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
-                       void *workspace, size_t workspace_bytes, void *stream, char *err)
+static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
+                           void *workspace, size_t workspace_bytes, const Tail *tail, void *stream, char *err)
 {
     int rc = epi_ekf_validate(d, err);
     if (rc != EPI_OK) return rc;
@@ -1374,11 +1347,11 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     KArgs ka{};
     ka.B = d->B; ka.T = d->T; ka.Sx = d->Sx; ka.Su = d->Su; ka.n_npi = d->n_npi; ka.L = d->L; ka.r_mode = d->r_mode; ka.q_mode = d->q_mode;
     ka.blk = lane_block_of(d); ka.nblk = (d->B + ka.blk - 1) / ka.blk;
-    const int shp = shape_of(d);
-    ka.quad = shp == EPI_SHAPE_QUAD ? 1 : 0;
-    ka.pair = shp == EPI_SHAPE_PAIR ? 1 : 0;
-    ka.x_full = ka.pair;
+    const int dev = current_device();
+    ka.quad = shape_of(d, dev) == EPI_SHAPE_QUAD ? 1 : 0;
     ka.stor = f32 ? 1 : 0;
+    ka.bk_from = d->T - 2; ka.bk_to = 0;
+    ka.c0 = 0; ka.cn = d->B;
     ka.mf.lo_is_zero = mi.lo_is_zero; ka.mf.phi_ge = mi.phi_ge; ka.mf.obs_clamp = mi.obs_clamp;
     ka.mf.obs_type = mi.obs_fixed ? EPI_OBS_NEWCASES : d->obs_type;
     ka.x_series = in->x_series; ka.u_series = in->u_series;
@@ -1419,6 +1392,10 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     ka.rankbuf = mi.generic ? (int32_t *)(ws + wl.rank) : nullptr;
     ka.pinv_pos0 = mi.flipped ? 0 : 1;
     ka.dense_flag = mi.generic ? (int *)(ws + wl.flag) : nullptr;
+    if (mi.generic) {
+        ka.hand_s = (double *)(ws + wl.hand_s); ka.hand_p = (double *)(ws + wl.hand_p); ka.hand_i = (int32_t *)(ws + wl.hand_i);
+        ka.hand_pitch = (int)padded_chains(d);
+    }
     {
         struct { uint32_t bit; const void *p; const char *n; } chk[] = {
             {EPI_OUT_U_OPT, out->u_opt, "u_opt"}, {EPI_OUT_S_MINUS, out->S_MINUS, "S_MINUS"},
@@ -1433,20 +1410,61 @@ int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_
     const bool smooth = ((om | om32) & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH)) ||
                         out->pinv_rank || out->status;
     hipStream_t st = (hipStream_t)stream;
-    int chunks = d->chunks;
-    if (chunks > kMaxChunks) chunks = kMaxChunks;
+    Launch L{};
+    L.dev = dev; L.phase = d->phase; L.time_pipe = d->time_pipe; L.smooth = smooth; L.tail = tail;
     // a time-varying Q_w is read per step by the dense kernels only
-    const int hint = (mi.generic && d->q_mode == 0) ? d->path_hint : 2;
+    L.hint = (mi.generic && d->q_mode == 0) ? d->path_hint : 2;
+    if (tail && (!ka.u_opt_smooth || d->phase != 0)) { set_err(err, "the sweep's scoring tail needs a full call (phase 0) with fp64 u_opt_smooth selected"); return EPI_ERR_BAD_ARG; }
     hipError_t e;
     switch (d->model) {
-    case EPI_MODEL_SIA3: e = launch_chain<3, 0, 1>(ka, d->phase, smooth, hint, chunks, st); break;
-    case EPI_MODEL_SIA6: e = launch_chain<6, 0, 1>(ka, d->phase, smooth, hint, chunks, st); break;
-    case EPI_MODEL_SIA3_BWD: e = launch_chain<3, 1, 1>(ka, d->phase, smooth, hint, chunks, st); break;
-    case EPI_MODEL_SIA6_BWD: e = launch_chain<6, 1, 1>(ka, d->phase, smooth, hint, chunks, st); break;
-    default: e = launch_chain<6, 0, 0>(ka, d->phase, smooth, hint, chunks, st); break;
+    case EPI_MODEL_SIA3: e = launch_chain<3, 0, 1>(ka, L, st); break;
+    case EPI_MODEL_SIA6: e = launch_chain<6, 0, 1>(ka, L, st); break;
+    case EPI_MODEL_SIA3_BWD: e = launch_chain<3, 1, 1>(ka, L, st); break;
+    case EPI_MODEL_SIA6_BWD: e = launch_chain<6, 1, 1>(ka, L, st); break;
+    default: e = launch_chain<6, 0, 0>(ka, L, st); break;
     }
     if (e != hipSuccess) return hip_fail(err, e, "kernel launch");
     return EPI_OK;
+}
+
+int epi_ekf_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
+                       void *workspace, size_t workspace_bytes, void *stream, char *err)
+{
+    return run_device_impl(d, in, out, workspace, workspace_bytes, nullptr, stream, err);
+}
+
+static int sweep_args_ok(const epi_batch_desc *d, const epi_sweep_desc *sd, const double *sp, const double *J0_prefix,
+                         const double *J1_prefix, double *J0, double *J1, int32_t *on_front, int32_t *i_opt, char *err)
+{
+    if (!d || !sd || sd->abi_version != EPIEKF_ABI_VERSION) { set_err(err, "bad sweep descriptor"); return EPI_ERR_BAD_ARG; }
+    if (d->model != EPI_MODEL_SIA6) { set_err(err, "the cost-weight sweep runs SIAlphaModelEKFOptControlled (EPI_MODEL_SIA6)"); return EPI_ERR_UNSUPPORTED; }
+    if (sd->t_hist < 1 || sd->t_hist >= d->T) { set_err(err, "t_hist must leave at least one horizon day: 1 <= t_hist < T"); return EPI_ERR_BAD_ARG; }
+    if (!sp || !J0_prefix || !J1_prefix || !J0 || !J1) { set_err(err, "NULL scoring array"); return EPI_ERR_BAD_ARG; }
+    if (on_front || i_opt) {
+        if (sd->R < 1 || sd->P < 1 || (int64_t)sd->R * sd->P != (int64_t)d->B) { set_err(err, "the Pareto filter needs whole regions: B == R * P"); return EPI_ERR_BAD_ARG; }
+        if (sd->P > 8192) { set_err(err, "more than 8192 points per region"); return EPI_ERR_UNSUPPORTED; }
+    }
+    if (d->storage != 0 || !(d->out_mask & EPI_OUT_U_OPT_SMOOTH)) { set_err(err, "the sweep scores the fp64 u_opt_smooth output: select it (storage 0)"); return EPI_ERR_BAD_ARG; }
+    return EPI_OK;
+}
+
+int epi_sweep_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, void *workspace,
+                         size_t workspace_bytes, const epi_sweep_desc *sd, const double *sp, const double *J0_prefix,
+                         const double *J1_prefix, double *J0, double *J1, int32_t *on_front, int32_t *i_opt, void *stream,
+                         char *err)
+{
+    int rc = sweep_args_ok(d, sd, sp, J0_prefix, J1_prefix, J0, J1, on_front, i_opt, err);
+    if (rc != EPI_OK) return rc;
+    Tail t{};
+    t.t_hist = sd->t_hist; t.R = sd->R; t.P = sd->P;
+    t.sp = sp; t.J0_prefix = J0_prefix; t.J1_prefix = J1_prefix; t.J0 = J0; t.J1 = J1; t.on_front = on_front; t.i_opt = i_opt;
+    if ((on_front || i_opt) && (size_t)2 * sd->P * sizeof(double) > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute((const void *)pareto_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)2 * sd->P * sizeof(double)));
+        if (e != hipSuccess) return hip_fail(err, e, "hipFuncSetAttribute");
+    }
+    epi_batch_desc full = *d;
+    full.phase = 0;
+    return run_device_impl(&full, in, out, workspace, workspace_bytes, &t, stream, err);
 }
 
 int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err)
@@ -1488,10 +1506,10 @@ int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void 
 // outlives the call (idle contexts wait in a per-device pool), so that the 250 calls per region of the unchanged
 // reference caller (TrainPredictPrescribeNPI.m:421-460) do not pay 50 hipMalloc/hipFree and 50 synchronous copies each.
 }   // extern "C"
-#include <mutex>
-#include <thread>
 namespace epi {
 constexpr size_t kStageBytes = (size_t)64 << 20;
+constexpr size_t kArenaKeepBytes = (size_t)2 << 30;   // an idle context keeps at most this much device memory
+constexpr int kPoolPerDevice = 4;                      // idle contexts kept per device (64 MiB of pinned memory each)
 struct HostCtx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -1523,6 +1541,7 @@ static std::mutex g_pool_mu;
 static std::vector<HostCtx *> g_pool;     // idle contexts of all devices
 static HostCtx *ctx_acquire(int device, hipError_t *e)
 {
+    if (device < 0 || device >= kMaxDevices) { *e = hipErrorInvalidDevice; return nullptr; }
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         for (size_t i = 0; i < g_pool.size(); i++)
@@ -1535,50 +1554,156 @@ static HostCtx *ctx_acquire(int device, hipError_t *e)
     if ((*e = hipHostMalloc((void **)&c->pinned, kStageBytes, hipHostMallocDefault)) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
+// back to the pool: a large arena is handed back to the device first (one big sweep must not keep tens of GB away from
+// the rest of the process), and a device keeps at most kPoolPerDevice idle contexts
 static void ctx_release(HostCtx *c)
 {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_pool.push_back(c);
+    if (c->arena_bytes > kArenaKeepBytes) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(c->arena);
+        c->arena = nullptr; c->arena_bytes = 0;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int same = 0;
+        for (HostCtx *o : g_pool) same += o->device == c->device;
+        if (same < kPoolPerDevice) { g_pool.push_back(c); return; }
+    }
+    delete c;
+}
+
+// The arrays of one host call on one context: every array is `rows` rows of which this call moves a strided piece
+// (columns [col0, col0 + cols) of a row of cols_full elements) to / from a contiguous device copy.  Calls whose arrays fit
+// the pinned buffer are packed there and moved by ONE copy each way; larger ones go row block by row block.
+struct HostIO {
+    struct Piece { const char *src; char *dst; size_t rows, width, pitch, off; };
+    std::vector<Piece> ins, outs;
+    size_t off = 0, in_bytes = 0;
+    size_t align = 256;
+    size_t add_in(const void *host, size_t rows, size_t elem, size_t cols_full, size_t col0, size_t cols)
+    {
+        ins.push_back(Piece{host ? (const char *)host + col0 * elem : nullptr, nullptr, rows, cols * elem, cols_full * elem, off});
+        const size_t o = off;
+        off += (rows * cols * elem + align - 1) / align * align;
+        in_bytes = off;
+        return o;
+    }
+    size_t add_out(void *host, size_t rows, size_t elem, size_t cols_full, size_t col0, size_t cols)
+    {
+        // host == NULL: the device copy exists (kernels write it) but nothing is copied back
+        outs.push_back(Piece{nullptr, host ? (char *)host + col0 * elem : nullptr, rows, cols * elem, cols_full * elem, off});
+        const size_t o = off;
+        off += (rows * cols * elem + align - 1) / align * align;
+        return o;
+    }
+    size_t reserve(size_t bytes)       // device-only scratch inside the same arena
+    {
+        off = (off + 255) & ~(size_t)255;
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    }
+    bool inputs_present() const
+    {
+        for (auto &p : ins) if (!p.src) return false;
+        return true;
+    }
+    // (outputs must all have been added before the first reserve() for the staged download to be one copy; the code
+    // below copies [in_bytes, out_end) where out_end is the end of the last output piece)
+    size_t out_end() const { return outs.empty() ? in_bytes : outs.back().off + outs.back().rows * outs.back().width; }
+    bool staged() const { return out_end() <= kStageBytes && in_bytes <= kStageBytes; }
+    hipError_t upload(HostCtx *cx, char *base) const
+    {
+        if (staged()) {
+            for (auto &p : ins)
+                for (size_t r = 0; r < p.rows; r++) memcpy(cx->pinned + p.off + r * p.width, p.src + r * p.pitch, p.width);
+            return in_bytes ? hipMemcpyAsync(base, cx->pinned, in_bytes, hipMemcpyHostToDevice, cx->stream) : hipSuccess;
+        }
+        for (auto &p : ins) {
+            const hipError_t e = hipMemcpy2DAsync(base + p.off, p.width, p.src, p.pitch, p.width, p.rows, hipMemcpyHostToDevice, cx->stream);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    // enqueues the copies back, waits for the stream, and (staged) scatters the rows into the caller's arrays
+    hipError_t download(HostCtx *cx, const char *base) const
+    {
+        hipError_t e;
+        if (staged()) {
+            const size_t end = out_end();
+            if (end > in_bytes && (e = hipMemcpyAsync(cx->pinned + in_bytes, base + in_bytes, end - in_bytes, hipMemcpyDeviceToHost, cx->stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(cx->stream)) != hipSuccess) return e;
+            for (auto &p : outs)
+                if (p.dst)
+                    for (size_t r = 0; r < p.rows; r++) memcpy(p.dst + r * p.pitch, cx->pinned + p.off + r * p.width, p.width);
+            return hipSuccess;
+        }
+        for (auto &p : outs)
+            if (p.dst && (e = hipMemcpy2DAsync(p.dst, p.pitch, base + p.off, p.width, p.width, p.rows, hipMemcpyDeviceToHost, cx->stream)) != hipSuccess) return e;
+        return hipStreamSynchronize(cx->stream);
+    }
+};
+
+// ekf_precheck's rules on HOST arrays ([rows][pitch] doubles, columns [lo, lo + n)): may these chains take the packed
+// kernels?  Ps_init and Ps_final bit-wise symmetric (values and NaN pattern), Q_w diagonal, s_init / Ps_init / diag(Q_w)
+// finite.  The host entry points have the arrays in host memory, so the check costs no device round trip.
+static bool host_precheck(int m, bool flipped, const epi_inputs *in, size_t pitch, size_t lo, size_t n)
+{
+    const double *Pi = flipped ? in->Ps_final : in->Ps_init, *Pf = flipped ? in->Ps_init : in->Ps_final;
+    const double *si = flipped ? in->s_final : in->s_init, *Q = in->Q;
+    auto nonfinite = [](double v) { return !(v - v == 0.0); };
+    auto same = [](double a, double b) { return a == b || (a != a && b != b); };
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i <= j; i++) {
+            const double *pu = Pi + (size_t)(i + m * j) * pitch + lo, *pl = Pi + (size_t)(j + m * i) * pitch + lo;
+            const double *fu = Pf + (size_t)(i + m * j) * pitch + lo, *fl = Pf + (size_t)(j + m * i) * pitch + lo;
+            const double *qu = Q + (size_t)(i + m * j) * pitch + lo, *ql = Q + (size_t)(j + m * i) * pitch + lo;
+            for (size_t c = 0; c < n; c++) {
+                if (nonfinite(pu[c])) return false;
+                if (i == j) { if (nonfinite(qu[c])) return false; continue; }
+                if (!same(pu[c], pl[c]) || !same(fu[c], fl[c]) || !(qu[c] == 0.0) || !(ql[c] == 0.0)) return false;
+            }
+        }
+    for (int i = 0; i < m; i++)
+        for (size_t c = 0; c < n; c++)
+            if (nonfinite(si[(size_t)i * pitch + lo + c])) return false;
+    return true;
 }
 
 // chains [lo, lo + n) of a host call on one context.  Per-chain arrays are [rows][B] in the caller's memory: the block is a
-// strided piece of each row.  Small calls are packed into the pinned buffer and moved by one copy each way.
+// strided piece of each row.
 static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_inputs *in, const epi_outputs *out, int lo, int n, char *err)
 {
     if (n <= 0) return EPI_OK;
     epi_batch_desc d = *d0;
-    const int Bfull = d0->B;
+    const size_t Bfull = (size_t)d0->B;
     d.B = n;
     const bool id_x = !in->x_series, id_u = !in->u_series;      // identity series: one series per chain, sliced with the chains
     if (id_x) d.Sx = n;
     if (id_u) d.Su = n;
-    const int m = MODEL_TABLE[d.model].m, mm = m * m;
+    const ModelInfo &mi = MODEL_TABLE[d.model];
+    const int m = mi.m, mm = m * m;
     const size_t T = (size_t)d.T;
-    struct Piece { const void *host; void *host_out; size_t rows, width, pitch_host; size_t off; };   // rows x width bytes
-    std::vector<Piece> ins, outs;
-    size_t off = 0;
-    auto add = [&](std::vector<Piece> &v, const void *h, void *ho, size_t rows, size_t elem, size_t cols_full, size_t col0, size_t cols) -> size_t {
-        Piece p{h ? (const char *)h + col0 * elem : nullptr, ho ? (char *)ho + col0 * elem : nullptr, rows, cols * elem, cols_full * elem, off};
-        v.push_back(p);
-        const size_t o = off;
-        off += (rows * cols * elem + 255) & ~(size_t)255;
-        return o;
-    };
+    HostIO io;
     epi_inputs din{};
     epi_outputs dout{};
     // inputs
-    const size_t o_xs = in->x_series ? add(ins, in->x_series, nullptr, 1, 4, Bfull, lo, n) : 0;
-    const size_t o_us = in->u_series ? add(ins, in->u_series, nullptr, 1, 4, Bfull, lo, n) : 0;
-    const size_t o_x = id_x ? add(ins, in->x, nullptr, T, 8, Bfull, lo, n) : add(ins, in->x, nullptr, T, 8, d0->Sx, 0, d0->Sx);
-    const size_t o_u = id_u ? add(ins, in->u, nullptr, T * d.n_npi, 8, Bfull, lo, n) : add(ins, in->u, nullptr, T * d.n_npi, 8, d0->Su, 0, d0->Su);
+    const size_t o_xs = in->x_series ? io.add_in(in->x_series, 1, 4, Bfull, lo, n) : 0;
+    const size_t o_us = in->u_series ? io.add_in(in->u_series, 1, 4, Bfull, lo, n) : 0;
+    const size_t o_x = id_x ? io.add_in(in->x, T, 8, Bfull, lo, n) : io.add_in(in->x, T, 8, d0->Sx, 0, d0->Sx);
+    const size_t o_u = id_u ? io.add_in(in->u, T * d.n_npi, 8, Bfull, lo, n) : io.add_in(in->u, T * d.n_npi, 8, d0->Su, 0, d0->Su);
     size_t o_rs = 0, o_rc = 0;
-    if (d.r_mode == 1) o_rs = id_x ? add(ins, in->R_series, nullptr, T, 8, Bfull, lo, n) : add(ins, in->R_series, nullptr, T, 8, d0->Sx, 0, d0->Sx);
-    else o_rc = add(ins, in->R_scalar, nullptr, 1, 8, Bfull, lo, n);
-    const size_t o_prm = add(ins, in->prm, nullptr, EPI_PRM_COUNT, 8, Bfull, lo, n);
-    const size_t o_si = add(ins, in->s_init, nullptr, m, 8, Bfull, lo, n), o_pi = add(ins, in->Ps_init, nullptr, mm, 8, Bfull, lo, n);
-    const size_t o_sf = add(ins, in->s_final, nullptr, m, 8, Bfull, lo, n), o_pf = add(ins, in->Ps_final, nullptr, mm, 8, Bfull, lo, n);
-    const size_t o_q = add(ins, in->Q, nullptr, (d.q_mode ? T : (size_t)1) * mm, 8, Bfull, lo, n);
-    const size_t in_bytes = off;
+    if (d.r_mode == 1) o_rs = id_x ? io.add_in(in->R_series, T, 8, Bfull, lo, n) : io.add_in(in->R_series, T, 8, d0->Sx, 0, d0->Sx);
+    else o_rc = io.add_in(in->R_scalar, 1, 8, Bfull, lo, n);
+    const size_t o_prm = io.add_in(in->prm, EPI_PRM_COUNT, 8, Bfull, lo, n);
+    const size_t o_si = io.add_in(in->s_init, m, 8, Bfull, lo, n), o_pi = io.add_in(in->Ps_init, mm, 8, Bfull, lo, n);
+    const size_t o_sf = io.add_in(in->s_final, m, 8, Bfull, lo, n), o_pf = io.add_in(in->Ps_final, mm, 8, Bfull, lo, n);
+    const size_t o_q = io.add_in(in->Q, (d.q_mode ? T : (size_t)1) * mm, 8, Bfull, lo, n);
+    if (!io.inputs_present()) { set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG; }
+    // the caller's arrays are in host memory: decide here which kernels run (what epi_ekf_precheck_device answers for
+    // device arrays), so that a host call enqueues one variant only and gets the overlapped launch
+    if (d.path_hint == 0 && mi.generic && d.q_mode == 0)
+        d.path_hint = host_precheck(m, mi.flipped != 0, in, Bfull, (size_t)lo, (size_t)n) ? 1 : 2;
     // outputs
     struct O { uint32_t bit; double *host; double **dev; size_t rows; };
     const size_t rU = T * d.n_npi, rS = T * m, rP = T * mm, r1 = T;
@@ -1590,12 +1715,12 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
                  {EPI_OUT_RHO, out->rho, &dout.rho, r1}};
     std::vector<size_t> o_out;
     for (auto &o : olist)
-        o_out.push_back(((d.out_mask & o.bit) && o.host) ? add(outs, nullptr, o.host, o.rows, 8, Bfull, lo, n) : (size_t)-1);
-    const size_t o_rank = out->pinv_rank ? add(outs, nullptr, out->pinv_rank, T, 4, Bfull, lo, n) : (size_t)-1;
-    const size_t o_stat = out->status ? add(outs, nullptr, out->status, 1, 4, Bfull, lo, n) : (size_t)-1;
-    const size_t io_bytes = off;
+        o_out.push_back(((d.out_mask & o.bit) && o.host) ? io.add_out(o.host, o.rows, 8, Bfull, lo, n) : (size_t)-1);
+    const size_t o_rank = out->pinv_rank ? io.add_out(out->pinv_rank, T, 4, Bfull, lo, n) : (size_t)-1;
+    const size_t o_stat = out->status ? io.add_out(out->status, 1, 4, Bfull, lo, n) : (size_t)-1;
     const size_t wsb = epi_ekf_workspace_bytes(&d);
-    hipError_t e = cx->reserve(io_bytes + wsb + 256);
+    const size_t o_ws = io.reserve(wsb);
+    hipError_t e = cx->reserve(io.off + 256);
     if (e != hipSuccess) return hip_fail(err, e, "device arena");
     char *base = cx->arena;
     din.x_series = in->x_series ? (const int32_t *)(base + o_xs) : nullptr;
@@ -1613,36 +1738,10 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     }
     if (o_rank != (size_t)-1) dout.pinv_rank = (int32_t *)(base + o_rank);
     if (o_stat != (size_t)-1) dout.status = (int32_t *)(base + o_stat);
-    void *ws = base + ((io_bytes + 255) & ~(size_t)255);
-    for (auto &p : ins)
-        if (!p.host) { set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG; }
-    const bool staged = io_bytes <= kStageBytes;
-    auto pack = [&](const Piece &p, char *dst) {       // caller's strided block -> contiguous rows
-        for (size_t r = 0; r < p.rows; r++) memcpy(dst + r * p.width, (const char *)p.host + r * p.pitch_host, p.width);
-    };
-    if (staged) {
-        for (auto &p : ins) pack(p, cx->pinned + p.off);
-        if ((e = hipMemcpyAsync(base, cx->pinned, in_bytes, hipMemcpyHostToDevice, cx->stream)) != hipSuccess) return hip_fail(err, e, "upload");
-    } else {
-        for (auto &p : ins)
-            if ((e = hipMemcpy2DAsync(base + p.off, p.width, p.host, p.pitch_host, p.width, p.rows, hipMemcpyHostToDevice, cx->stream)) != hipSuccess)
-                return hip_fail(err, e, "upload");
-    }
-    const int rc = epi_ekf_run_device(&d, &din, &dout, wsb ? ws : nullptr, wsb, cx->stream, err);
+    if ((e = io.upload(cx, base)) != hipSuccess) return hip_fail(err, e, "upload");
+    const int rc = epi_ekf_run_device(&d, &din, &dout, wsb ? base + o_ws : nullptr, wsb, cx->stream, err);
     if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
-    if (staged) {
-        if (io_bytes > in_bytes &&
-            (e = hipMemcpyAsync(cx->pinned + in_bytes, base + in_bytes, io_bytes - in_bytes, hipMemcpyDeviceToHost, cx->stream)) != hipSuccess)
-            return hip_fail(err, e, "download");
-        if ((e = hipStreamSynchronize(cx->stream)) != hipSuccess) return hip_fail(err, e, "kernel execution");
-        for (auto &p : outs)
-            for (size_t r = 0; r < p.rows; r++) memcpy((char *)p.host_out + r * p.pitch_host, cx->pinned + p.off + r * p.width, p.width);
-    } else {
-        for (auto &p : outs)
-            if ((e = hipMemcpy2DAsync(p.host_out, p.pitch_host, base + p.off, p.width, p.width, p.rows, hipMemcpyDeviceToHost, cx->stream)) != hipSuccess)
-                return hip_fail(err, e, "download");
-        if ((e = hipStreamSynchronize(cx->stream)) != hipSuccess) return hip_fail(err, e, "kernel execution");
-    }
+    if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download");
     return EPI_OK;
 }
 static int host_args_ok(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, char *err)
@@ -1655,6 +1754,75 @@ static int host_args_ok(const epi_batch_desc *d, const epi_inputs *in, const epi
     if (!in->x_series && d->Sx != d->B) { set_err(err, "identity x_series needs Sx == B"); return EPI_ERR_BAD_ARG; }
     if (!in->u_series && d->Su != d->B) { set_err(err, "identity u_series needs Su == B"); return EPI_ERR_BAD_ARG; }
     return EPI_OK;
+}
+
+// One worker thread per device for the *_multi entry points (created on first use, parked on a condition variable between
+// calls, joined by epi_host_pool_release): a call hands every block of chains / regions to the worker of its device and
+// waits; blocks that name the same device run one after the other.
+struct DevWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    bool stop = false;
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                job = std::move(q.front());
+                q.pop_front();
+            }
+            job();
+        }
+    }
+};
+static std::mutex g_worker_mu;
+static DevWorker *g_workers[kMaxDevices];
+static void worker_submit(int device, std::function<void()> job)
+{
+    DevWorker *w;
+    {
+        std::lock_guard<std::mutex> lk(g_worker_mu);
+        if (!g_workers[device]) {
+            g_workers[device] = new DevWorker();
+            g_workers[device]->th = std::thread([p = g_workers[device]] { p->loop(); });
+        }
+        w = g_workers[device];
+    }
+    { std::lock_guard<std::mutex> lk(w->mu); w->q.push_back(std::move(job)); }
+    w->cv.notify_one();
+}
+static void workers_release_all()
+{
+    for (int dev = 0; dev < kMaxDevices; dev++) {
+        DevWorker *w;
+        { std::lock_guard<std::mutex> lk(g_worker_mu); w = g_workers[dev]; g_workers[dev] = nullptr; }
+        if (!w) continue;
+        { std::lock_guard<std::mutex> lk(w->mu); w->stop = true; }
+        w->cv.notify_one();
+        w->th.join();
+        delete w;
+    }
+}
+// runs job(r) for r = 0 .. n-1 on the workers of devices dev_of(r) and waits for all of them
+static void run_on_devices(int n, const std::function<int(int)> &dev_of, const std::function<void(int)> &job)
+{
+    if (n == 1) { job(0); return; }          // one block: the calling thread does it
+    std::mutex mu;
+    std::condition_variable cv;
+    int left = n;
+    for (int r = 0; r < n; r++)
+        worker_submit(dev_of(r), [&, r] {
+            job(r);
+            std::lock_guard<std::mutex> lk(mu);
+            if (--left == 0) cv.notify_one();
+        });
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return left == 0; });
 }
 }   // namespace epi
 extern "C" {
@@ -1671,29 +1839,172 @@ int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_ou
     return rc;
 }
 
+static int multi_devices_ok(int n_devices, const int *device_ids, char *err)
+{
+    if (n_devices < 1 || n_devices > kMaxDevices) { set_err(err, "n_devices must be 1..64"); return EPI_ERR_BAD_ARG; }
+    for (int r = 0; r < n_devices; r++) {
+        const int dev = device_ids ? device_ids[r] : r;
+        if (dev < 0 || dev >= kMaxDevices) { set_err(err, "device id out of range 0..63"); return EPI_ERR_BAD_ARG; }
+    }
+    return EPI_OK;
+}
+
 int epi_ekf_run_host_multi(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, int n_devices,
                            const int *device_ids, char *err)
 {
     int rc = host_args_ok(d, in, out, err);
     if (rc != EPI_OK) return rc;
-    if (n_devices < 1 || n_devices > 64) { set_err(err, "n_devices must be 1..64"); return EPI_ERR_BAD_ARG; }
+    if ((rc = multi_devices_ok(n_devices, device_ids, err)) != EPI_OK) return rc;
     const int per = (d->B + n_devices - 1) / n_devices;
     std::vector<int> rcs((size_t)n_devices, EPI_OK);
     std::vector<std::vector<char>> errs((size_t)n_devices, std::vector<char>(256, 0));
-    std::vector<std::thread> th;
-    for (int r = 0; r < n_devices; r++) {
+    auto dev_of = [&](int r) { return device_ids ? device_ids[r] : r; };
+    run_on_devices(n_devices, dev_of, [&](int r) {
         const int lo = r * per < d->B ? r * per : d->B, n = (lo + per <= d->B ? per : d->B - lo);
-        const int dev = device_ids ? device_ids[r] : r;
-        th.emplace_back([=, &rcs, &errs]() {
-            if (n <= 0) return;
-            hipError_t e = hipSuccess;
-            HostCtx *cx = ctx_acquire(dev, &e);
-            if (!cx || e != hipSuccess) { if (cx) ctx_release(cx); rcs[(size_t)r] = hip_fail(errs[(size_t)r].data(), e, "hipSetDevice / context"); return; }
-            rcs[(size_t)r] = run_host_block(cx, d, in, out, lo, n, errs[(size_t)r].data());
-            ctx_release(cx);
-        });
+        if (n <= 0) return;
+        hipError_t e = hipSuccess;
+        HostCtx *cx = ctx_acquire(dev_of(r), &e);
+        if (!cx || e != hipSuccess) { if (cx) ctx_release(cx); rcs[(size_t)r] = hip_fail(errs[(size_t)r].data(), e, "hipSetDevice / context"); return; }
+        rcs[(size_t)r] = run_host_block(cx, d, in, out, lo, n, errs[(size_t)r].data());
+        ctx_release(cx);
+    });
+    for (int r = 0; r < n_devices; r++)
+        if (rcs[(size_t)r] != EPI_OK) { set_err(err, errs[(size_t)r].data()); return rcs[(size_t)r]; }
+    return EPI_OK;
+}
+
+// regions [r0, r0 + Rd) of the sweep on one context (see epi_sweep_prescribe_host)
+static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_prescribe_inputs *in, const epi_prescribe_outputs *out,
+                           int r0, int Rd, char *err)
+{
+    if (Rd <= 0) return EPI_OK;
+    const size_t R = (size_t)pd->R, P = (size_t)pd->P, T = (size_t)pd->T, n = (size_t)pd->n_npi;
+    const size_t Bd = (size_t)Rd * P, Bfull = R * P, c0 = (size_t)r0 * P;
+    const bool extras = pd->out_mask != 0;
+    // the filter's descriptor for this block: chain c = region * P + ll reads series `region`
+    epi_batch_desc d{};
+    d.abi_version = EPIEKF_ABI_VERSION; d.model = EPI_MODEL_SIA6; d.B = (int32_t)Bd; d.T = pd->T; d.Sx = Rd; d.Su = Rd;
+    d.n_npi = pd->n_npi; d.L = pd->L; d.order = pd->order; d.obs_type = pd->obs_type; d.r_mode = 1; d.q_mode = 0;
+    d.out_mask = pd->out_mask | EPI_OUT_U_OPT_SMOOTH | (out->S_opt ? EPI_OUT_S_SMOOTH : 0u);
+    d.shape = pd->shape; d.time_pipe = pd->time_pipe;
+    {
+        epi_inputs hin{};
+        hin.s_init = in->s_init; hin.Ps_init = in->Ps_init; hin.s_final = in->s_final; hin.Ps_final = in->Ps_final; hin.Q = in->Q;
+        d.path_hint = host_precheck(6, false, &hin, R, (size_t)r0, (size_t)Rd) ? 1 : 2;
     }
-    for (auto &t : th) t.join();
+    // per-chain extras come back in the classic layout; without them the filter writes the layout it runs fastest in
+    d.lane_block = extras ? 0 : epi_ekf_preferred_lane_block(&d);
+    if (d.lane_block >= d.B) d.lane_block = 0;
+    int rc = epi_ekf_validate(&d, err);
+    if (rc != EPI_OK) return rc;
+    const size_t blk = d.lane_block ? (size_t)d.lane_block : Bd, nblk = (Bd + blk - 1) / blk, Bp = nblk * blk;
+
+    HostIO io;
+    const size_t o_x = io.add_in(in->x, T, 8, R, r0, Rd), o_u = io.add_in(in->u, T * n, 8, R, r0, Rd);
+    const size_t o_rs = io.add_in(in->R_series, T, 8, R, r0, Rd), o_eps = io.add_in(in->eps, 1, 8, P, 0, P);
+    // the per-region rows, contiguous and in the order of the per-chain rows sweep_expand writes
+    io.off = (io.off + 255) & ~(size_t)255;
+    io.align = 8;
+    struct Row { const double *host; size_t rows; };
+    const Row rows[] = {{in->prm, EPI_PRM_COUNT}, {in->s_init, 6}, {in->Ps_init, 36}, {in->s_final, 6}, {in->Ps_final, 36},
+                        {in->Q, 36}, {in->sp, EPI_SIM_PRM_COUNT}, {in->J0_prefix, 1}, {in->J1_prefix, 1}};
+    size_t o_reg = 0, nrows = 0;
+    for (auto &rw : rows) {
+        const size_t o = io.add_in(rw.host, rw.rows, 8, R, r0, Rd);
+        if (nrows == 0) o_reg = o;
+        nrows += rw.rows;
+    }
+    io.align = 256;
+    io.off = (io.off + 255) & ~(size_t)255; io.in_bytes = io.off;
+    if (!io.inputs_present()) { set_err(err, "NULL input array"); return EPI_ERR_BAD_ARG; }
+    // outputs, in one run of the arena so that a small call downloads them with one copy
+    const size_t o_j0 = io.add_out(out->J0, 1, 8, Bfull, c0, Bd), o_j1 = io.add_out(out->J1, 1, 8, Bfull, c0, Bd);
+    const size_t o_of = io.add_out(out->on_front, 1, 4, Bfull, c0, Bd), o_io = io.add_out(out->i_opt, 1, 4, R, r0, Rd);
+    const size_t o_uo = io.add_out(out->u_opt, T * n, 8, R, r0, Rd), o_so = io.add_out(out->S_opt, T * 6, 8, R, r0, Rd);
+    epi_outputs dout{};
+    struct O { uint32_t bit; double *host; double **dev; size_t rows; };
+    const epi_outputs &ex = out->extras;
+    O olist[] = {{EPI_OUT_U_OPT, ex.u_opt, &dout.u_opt, T * n}, {EPI_OUT_U_OPT_SMOOTH, ex.u_opt_smooth, &dout.u_opt_smooth, T * n},
+                 {EPI_OUT_S_MINUS, ex.S_MINUS, &dout.S_MINUS, T * 6}, {EPI_OUT_S_PLUS, ex.S_PLUS, &dout.S_PLUS, T * 6},
+                 {EPI_OUT_S_SMOOTH, ex.S_SMOOTH, &dout.S_SMOOTH, T * 6}, {EPI_OUT_P_MINUS, ex.P_MINUS, &dout.P_MINUS, T * 36},
+                 {EPI_OUT_P_PLUS, ex.P_PLUS, &dout.P_PLUS, T * 36}, {EPI_OUT_P_SMOOTH, ex.P_SMOOTH, &dout.P_SMOOTH, T * 36},
+                 {EPI_OUT_K_GAIN, ex.K_GAIN, &dout.K_GAIN, T * 6}, {EPI_OUT_INNOVATIONS, ex.innovations, &dout.innovations, T},
+                 {EPI_OUT_RHO, ex.rho, &dout.rho, T}};
+    std::vector<size_t> o_ex;
+    for (auto &o : olist) {
+        if ((pd->out_mask & o.bit) && !o.host) { set_err(err, "extras: output selected but NULL"); return EPI_ERR_BAD_ARG; }
+        o_ex.push_back((pd->out_mask & o.bit) ? io.add_out(o.host, o.rows, 8, Bfull, c0, Bd) : (size_t)-1);
+    }
+    // device-only: expanded per-chain rows, the series map, filter outputs that do not leave the device, workspace
+    const size_t o_chain = io.reserve(nrows * Bd * 8), o_ser = io.reserve(Bd * 4);
+    const size_t o_uos = (pd->out_mask & EPI_OUT_U_OPT_SMOOTH) ? (size_t)-1 : io.reserve(T * n * Bp * 8);
+    const size_t o_ss = ((pd->out_mask & EPI_OUT_S_SMOOTH) || !out->S_opt) ? (size_t)-1 : io.reserve(T * 6 * Bp * 8);
+    const size_t wsb = epi_ekf_workspace_bytes(&d);
+    const size_t o_ws = io.reserve(wsb);
+    hipError_t e = cx->reserve(io.off + 256);
+    if (e != hipSuccess) return hip_fail(err, e, "device arena");
+    char *base = cx->arena;
+    if ((e = io.upload(cx, base)) != hipSuccess) return hip_fail(err, e, "upload");
+    double *chain = (double *)(base + o_chain);
+    int32_t *series = (int32_t *)(base + o_ser);
+    hipLaunchKernelGGL(sweep_expand, dim3((unsigned)((Bd + 255) / 256), 8), dim3(256), 0, cx->stream, (int)nrows, Rd, (int)P,
+                       (int)EPI_PRM_EPSILON, (const double *)(base + o_reg), (const double *)(base + o_eps), chain, series);
+    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "sweep_expand launch");
+    epi_inputs din{};
+    din.x_series = series; din.u_series = series;
+    din.x = (const double *)(base + o_x); din.u = (const double *)(base + o_u); din.R_series = (const double *)(base + o_rs);
+    size_t row = 0;
+    auto take = [&](size_t nr) { const double *p = chain + row * Bd; row += nr; return p; };
+    din.prm = take(EPI_PRM_COUNT); din.s_init = take(6); din.Ps_init = take(36); din.s_final = take(6); din.Ps_final = take(36);
+    din.Q = take(36);
+    const double *sp = take(EPI_SIM_PRM_COUNT), *j0p = take(1), *j1p = take(1);
+    {
+        size_t k = 0;
+        for (auto &o : olist) { if (o_ex[k] != (size_t)-1) *o.dev = (double *)(base + o_ex[k]); k++; }
+    }
+    if (!dout.u_opt_smooth) dout.u_opt_smooth = (double *)(base + o_uos);
+    if (!dout.S_SMOOTH && out->S_opt) dout.S_SMOOTH = (double *)(base + o_ss);
+    epi_sweep_desc sd{};
+    sd.abi_version = EPIEKF_ABI_VERSION; sd.R = Rd; sd.P = (int32_t)P; sd.t_hist = pd->t_hist;
+    rc = epi_sweep_run_device(&d, &din, &dout, wsb ? base + o_ws : nullptr, wsb, &sd, sp, j0p, j1p, (double *)(base + o_j0),
+                              (double *)(base + o_j1), (int32_t *)(base + o_of), (int32_t *)(base + o_io), cx->stream, err);
+    if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
+    struct G { double *host; const double *src; size_t off; int rows; };
+    const G gs[] = {{out->u_opt, dout.u_opt_smooth, o_uo, (int)n}, {out->S_opt, dout.S_SMOOTH, o_so, 6}};
+    for (auto &g : gs) {
+        if (!g.host) continue;
+        const size_t cnt = T * (size_t)g.rows * (size_t)Rd;
+        hipLaunchKernelGGL(sweep_gather_opt, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, cx->stream, (int)T, g.rows, Rd, (int)P,
+                           (int)blk, (int)nblk, (const int32_t *)(base + o_io), g.src, (double *)(base + g.off));
+        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "sweep_gather_opt launch");
+    }
+    if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download");
+    return EPI_OK;
+}
+
+int epi_sweep_prescribe_host(const epi_prescribe_desc *d, const epi_prescribe_inputs *in, const epi_prescribe_outputs *out,
+                             int n_devices, const int *device_ids, char *err)
+{
+    if (!d || !in || !out || d->abi_version != EPIEKF_ABI_VERSION) { set_err(err, "bad prescribe descriptor"); return EPI_ERR_BAD_ARG; }
+    if (d->R < 1 || d->P < 1 || (int64_t)d->R * d->P > ((int64_t)1 << 23)) { set_err(err, "R, P must be >= 1 and R * P <= 2^23"); return EPI_ERR_BAD_ARG; }
+    if (d->P > 8192) { set_err(err, "more than 8192 points per region"); return EPI_ERR_UNSUPPORTED; }
+    if (d->t_hist < 1 || d->t_hist >= d->T) { set_err(err, "t_hist must leave at least one horizon day: 1 <= t_hist < T"); return EPI_ERR_BAD_ARG; }
+    if (d->out_mask & ~(uint32_t)EPI_OUT_ALL) { set_err(err, "unknown bits in out_mask"); return EPI_ERR_BAD_ARG; }
+    int rc = multi_devices_ok(n_devices, device_ids, err);
+    if (rc != EPI_OK) return rc;
+    const int per = (d->R + n_devices - 1) / n_devices;
+    std::vector<int> rcs((size_t)n_devices, EPI_OK);
+    std::vector<std::vector<char>> errs((size_t)n_devices, std::vector<char>(256, 0));
+    auto dev_of = [&](int r) { return device_ids ? device_ids[r] : r; };
+    run_on_devices(n_devices, dev_of, [&](int r) {
+        const int lo = r * per < d->R ? r * per : d->R, n = (lo + per <= d->R ? per : d->R - lo);
+        if (n <= 0) return;
+        hipError_t e = hipSuccess;
+        HostCtx *cx = ctx_acquire(dev_of(r), &e);
+        if (!cx || e != hipSuccess) { if (cx) ctx_release(cx); rcs[(size_t)r] = hip_fail(errs[(size_t)r].data(), e, "hipSetDevice / context"); return; }
+        rcs[(size_t)r] = prescribe_block(cx, d, in, out, lo, n, errs[(size_t)r].data());
+        ctx_release(cx);
+    });
     for (int r = 0; r < n_devices; r++)
         if (rcs[(size_t)r] != EPI_OK) { set_err(err, errs[(size_t)r].data()); return rcs[(size_t)r]; }
     return EPI_OK;
@@ -1701,9 +2012,13 @@ int epi_ekf_run_host_multi(const epi_batch_desc *d, const epi_inputs *in, const 
 
 void epi_host_pool_release(void)
 {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    for (HostCtx *c : g_pool) delete c;
-    g_pool.clear();
+    workers_release_all();
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (HostCtx *c : g_pool) delete c;
+        g_pool.clear();
+    }
+    helpers_release_all();
 }
 
 int epi_calib_copy_f64_device(const double *src, double *dst, size_t n, void *stream, char *err)
@@ -1906,6 +2221,64 @@ int epi_npi_cost_host(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t w
     if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
     return h.finish(epi_npi_cost_device(B, T, n_npi, Su, weights_per_day, (const int32_t *)dus, (const double *)dn,
                                         (const double *)du, (const double *)dw, (double *)d0, (double *)d1, nullptr, err), err);
+}
+
+int epi_preprocess_host(const epi_pre_desc *d, const double *cases, const double *deaths, const double *population,
+                        const double *ip, const epi_pre_outputs *out, int device, char *err)
+{
+    if (!d || !out || d->S < 1 || d->T < 1 || d->n_npi < 0 || d->n_npi > EPI_MAX_NPI) { set_err(err, "bad preprocessing descriptor"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    const size_t TS = (size_t)d->T * d->S * 8;
+    HostStage h;
+    const void *dc = h.in(cases, TS), *dd = h.in(deaths, TS), *dp = h.in(population, (size_t)d->S * 8);
+    const void *dip = h.in(ip, TS * (size_t)d->n_npi);
+    epi_pre_outputs dout{};
+    dout.new_refined = (double *)h.out(out->new_refined, TS); dout.new_smoothed = (double *)h.out(out->new_smoothed, TS);
+    dout.zero_lag = (double *)h.out(out->zero_lag, TS); dout.x_new = (double *)h.out(out->x_new, TS);
+    dout.x_total = (double *)h.out(out->x_total, TS); dout.R_v = (double *)h.out(out->R_v, TS);
+    dout.fatality = (double *)h.out(out->fatality, TS); dout.I0 = (double *)h.out(out->I0, (size_t)d->S * 8);
+    dout.ip_filled = (double *)h.out(out->ip_filled, TS * (size_t)d->n_npi);
+    const size_t wsb = epi_preprocess_workspace_bytes(d);
+    void *ws = nullptr;
+    if (wsb && h.e == hipSuccess && (h.e = hipMalloc(&ws, wsb)) == hipSuccess) h.allocs.push_back(ws);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_preprocess_device(d, (const double *)dc, (const double *)dd, (const double *)dp, (const double *)dip, &dout,
+                                          ws, wsb, nullptr, err), err);
+}
+
+int epi_nnls_affine_fit_host(const epi_nnls_desc *d, const double *X, const double *y, double *a, double *b,
+                             double *min_err, int32_t *iters, int32_t *flag, int device, char *err)
+{
+    if (!d || d->S < 1 || d->D < 1 || d->n < 1 || d->n > EPI_MAX_NPI) { set_err(err, "bad NNLS descriptor"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    const size_t S = d->S;
+    HostStage h;
+    const void *dX = h.in(X, (size_t)d->D * d->n * S * 8), *dy = h.in(y, (size_t)d->D * S * 8);
+    void *da = h.out(a, (size_t)d->n * S * 8), *db = h.out(b, S * 8), *dm = h.out(min_err, S * 8);
+    void *di = h.out(iters, S * 4), *df = h.out(flag, S * 4);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_nnls_affine_fit_device(d, (const double *)dX, (const double *)dy, (double *)da, (double *)db, (double *)dm,
+                                               (int32_t *)di, (int32_t *)df, nullptr, err), err);
+}
+
+int epi_random_npi_mc_host(const epi_mc_desc *d, const double *sp, const double *u_min, const double *z,
+                           const double *J0_prefix, const double *J1_prefix, double *u_out, double *J0, double *J1,
+                           int device, char *err)
+{
+    if (!d || d->R < 1 || d->n_scen < 1 || d->K < 1 || d->n_npi < 1 || d->n_npi > EPI_MAX_NPI ||
+        (int64_t)d->R * d->n_scen > (int64_t)1 << 30) { set_err(err, "bad Monte-Carlo scenario descriptor"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    const size_t R = d->R, B = R * (size_t)d->n_scen, K = d->K;
+    HostStage h;
+    const void *dsp = h.in(sp, (size_t)EPI_SIM_PRM_COUNT * R * 8), *dum = h.in(u_min, (size_t)d->n_npi * R * 8);
+    const void *dz = h.in(z, K * 3 * B * 8), *dj0 = h.in(J0_prefix, R * 8), *dj1 = h.in(J1_prefix, R * 8);
+    void *du = h.out(u_out, K * (size_t)d->n_npi * B * 8), *d0 = h.out(J0, B * 8), *d1 = h.out(J1, B * 8);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_random_npi_mc_device(d, (const double *)dsp, (const double *)dum, (const double *)dz, (const double *)dj0,
+                                             (const double *)dj1, (double *)du, (double *)d0, (double *)d1, nullptr, err), err);
 }
 
 int epi_rt_expfit_validate(const epi_rt_desc *d, char *err)

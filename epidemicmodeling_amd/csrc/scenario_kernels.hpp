@@ -185,3 +185,39 @@ __global__ __launch_bounds__(256) void si_controlled(int B, int K, int Sa, doubl
         s_out[(size_t)(t + 1) * B + c] = s; i_out[(size_t)(t + 1) * B + c] = i;
     }
 }
+
+// ---------------------------------------------------------------------------
+// the cost-weight sweep from per-region inputs (epi_sweep_prescribe_host)
+// ---------------------------------------------------------------------------
+// Tools/TrainPredictPrescribeNPI.m:421-460 runs the SAME region inputs with params.epsilon = human_npi_cost_factor(ll):
+// chain c = region * P + ll.  Per-region rows [nrows][R] become per-chain rows [nrows][R * P] on the device (a host caller
+// sends R columns, not R * P); row `eps_row` is the cost-weight grid instead, and `series` [R * P] receives the region
+// of every chain (its x / u / R_v series).
+__global__ __launch_bounds__(256) void sweep_expand(int nrows, int R, int P, int eps_row, const double *__restrict__ src,
+                                                    const double *__restrict__ eps, double *__restrict__ dst,
+                                                    int32_t *__restrict__ series)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int B = R * P;
+    if (c >= B) return;
+    const int r = c / P;
+    if (blockIdx.y == 0 && series) series[c] = r;
+    for (int row = blockIdx.y; row < nrows; row += gridDim.y)
+        dst[(size_t)row * B + c] = (row == eps_row) ? eps[c - r * P] : src[(size_t)row * R + r];
+}
+
+// The prescription (:624-633 picks I_opt; the plan of that cost weight is what the caller keeps): column
+// c = r * P + i_opt[r] of a filter output [T][rows][chains] (classic or chain-blocked, see Lay) -> dst [T][rows][R]
+__global__ __launch_bounds__(256) void sweep_gather_opt(int T, int rows, int R, int P, int blk, int nblk,
+                                                        const int32_t *__restrict__ i_opt, const double *__restrict__ src,
+                                                        double *__restrict__ dst)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)T * rows * R) return;
+    const int r = (int)(idx % (size_t)R);
+    const int row = (int)((idx / (size_t)R) % (size_t)rows);
+    const size_t t = idx / ((size_t)R * rows);
+    const int c = r * P + i_opt[r];
+    const int cb = c / blk, cr = c - cb * blk;
+    dst[idx] = src[((t * (size_t)nblk + cb) * rows + row) * blk + cr];
+}

@@ -34,10 +34,19 @@
  * (Tools/TrainPredictPrescribeNPI.m:421-460).
  *
  * Ownership / threading / errors: the caller owns every buffer; the library
- * never frees or retains caller memory; calls are re-entrant and keep no global
- * state; all device work of a call is enqueued on the caller's stream.  Return
- * value 0 or a negative epi_status; `err` (256 bytes, may be NULL) receives the
- * reference's own error() text for the four reference errors.
+ * never frees or retains caller memory; every entry point may be called from
+ * several threads at once; all device work of a *_device call is enqueued on
+ * the caller's stream (stages that are off the critical path run on a helper
+ * stream that is forked from and joined back into the caller's stream, so the
+ * call behaves like work on that one stream, also under stream capture).
+ * What the library keeps between calls, all of it freed by
+ * epi_host_pool_release(): the CU count of each device it has seen, idle
+ * helper streams (one per concurrent call and device, with their events), and
+ * for the *_host entry points a pool of contexts per device (stream, device
+ * arena, pinned staging buffer) and one worker thread per device used by the
+ * *_multi calls.  Return value 0 or a negative epi_status; `err` (256 bytes,
+ * may be NULL) receives the reference's own error() text for the four
+ * reference errors.
  */
 #ifndef EPIEKF_H
 #define EPIEKF_H
@@ -50,7 +59,7 @@
 extern "C" {
 #endif
 
-#define EPIEKF_ABI_VERSION 2
+#define EPIEKF_ABI_VERSION 3
 
 /* which reference function the chain runs */
 typedef enum epi_model {
@@ -119,17 +128,12 @@ typedef struct epi_batch_desc {
                              1 = epi_ekf_precheck_device() said the batch qualifies for the symmetric-packed
                              kernels (Ps_init bit-wise symmetric, Q_w diagonal): enqueue only those;
                              2 = dense kernels only */
-    int32_t chunks;       /* > 1: split the chains of a full call (phase 0) into this many chunks, each
-                             enqueued on its own helper stream, so that one chunk's (chain, step)-parallel
-                             eks_pinv grid fills the SIMDs the other chunks' one-wave-per-SIMD sequential
-                             kernels leave idle; 0/1: one chunk on the caller's stream; -1: "rounds + tail" (the
-                             waves beyond a whole number of one-wave-per-SIMD rounds form the second chunk);
-                             -2: "pipelined halves" (generic models, path_hint = 1): the second half's forward
-                             kernel and the first half's eks_pinv grid share the SIMDs;
-                             -3: force "pipelined in time" (forward kernel in four time segments, each followed by the
-                             eks_pinv grid of its days on a second stream) -- what 0 / 1 choose by themselves for a full
-                             call of a batch that leaves a quarter of the SIMDs idle (generic models, path_hint = 1,
-                             R_v a per-day series, T >= 128) */
+    int32_t time_pipe;    /* a full call (phase 0) of a generic model on the packed kernels (path_hint = 1, R_v a per-day
+                             series, T >= 128) may run "pipelined in time": the forward kernel in five time segments (40, 30,
+                             20, 8, 2 % of the days), each followed by the eks_pinv grid of its days on a helper stream, so that
+                             only the last days' pinv stands between the forward pass and the smoother.  0 = the library
+                             decides (on when the batch leaves a quarter of the SIMDs idle -- the shards of the sweep on 2,
+                             4, 8 GPUs), 1 = on, -1 = off.  Results are bit-identical either way. */
     int32_t lane_block;   /* layout of the OUTPUT arrays (and of the workspace) of epi_ekf_run_device.  0 or >= B: the
                              classic [T][rows][B].  blk in 1..B-1 (8 recommended): chain-blocked,
                              element (t, row, c) at ((t*nblk + c/blk)*rows + row)*blk + c%blk, nblk = ceil(B/blk) --
@@ -141,16 +145,15 @@ typedef struct epi_batch_desc {
                              1 = one lane per chain (ekf_fwd_sym / eks_bwd_sym: least total work, what a batch that fills
                              the chip wants), 2 = four lanes per chain (ekf_fwd_quad / eks_bwd_quad: every 6 x 6 matrix as
                              a 2 x 2 grid of 3 x 3 blocks over a DPP quad; a ~2x shorter per-day instruction stream and
-                             4x the wavefronts, what a batch that does NOT fill the chip wants -- DESIGN.md 4), 3 = two lanes
-                             per chain (ekf_fwd_pair / eks_bwd_pair: rows 1-3 / 4-6 of every matrix; R_v a per-day series
-                             only, else 1 is used).  Results are bit-identical in all shapes.  Ignored by the other models. */
+                             4x the wavefronts, what a batch that does NOT fill the chip wants -- DESIGN.md 4).
+                             Results are bit-identical in both shapes.  Ignored by the other models. */
     int32_t storage;      /* element type of the OUTPUT arrays: 0 = fp64 (the reference's), 1 = fp32 storage with fp64
                              register arithmetic (BASELINE config 5): every selected output is the fp64 result rounded
                              once to fp32; the forward quantities the smoother reads back stay fp64 in the workspace.
                              epi_ekf_run_device only. */
 } epi_batch_desc;
 
-typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_PAIR = 3 } epi_shape;
+typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2 } epi_shape;
 
 typedef struct epi_inputs {
     const int32_t *x_series; /* [B] or NULL */
@@ -178,8 +181,8 @@ size_t epi_ekf_workspace_bytes(const epi_batch_desc *d);        /* device scratc
 int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err);
 
 /* The lane_block that matches the way epi_ekf_run_device will launch this batch on the current device: the number of
- * chains one wavefront handles (64, or fewer when the launch is split into equally full rounds; 16 / 32 where the 6-state
- * models run four / two lanes per chain, see `shape`).  With it every
+ * chains one wavefront handles (64, or fewer when the launch is split into equally full rounds; 16 where the 6-state
+ * models run four lanes per chain, see `shape`).  With it every
  * wavefront's loads and stores of a step are one contiguous piece per array -- the fastest of the blocked layouts
  * (DESIGN.md 3).  Returns 0 for an invalid descriptor. */
 int epi_ekf_preferred_lane_block(const epi_batch_desc *d);
@@ -208,7 +211,9 @@ int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_ou
 int epi_ekf_run_host_multi(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out,
                            int n_devices, const int *device_ids, char *err);
 
-/* Frees every pooled context (device arenas, pinned buffers, streams).  Optional: call before unloading the library. */
+/* Frees everything the library keeps between calls: pooled host contexts (device arenas, pinned buffers, streams), idle
+ * helper streams and their events, and the *_multi worker threads.  Optional: call before unloading the library.  Not to be
+ * called while another thread is inside a library call. */
 void epi_host_pool_release(void);
 
 /* ---- forward simulators and cost (Tools/SIalpha_Controlled.m, SEIRP.m, NPICost.m) ---- */
@@ -288,6 +293,69 @@ int epi_random_npi_mc_device(const epi_mc_desc *d, const double *sp, const doubl
  * NULL.  P <= 8192 (the points of a region are staged in LDS). */
 int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double *J1, int32_t *on_front,
                             int32_t *i_opt, void *stream, char *err);
+
+/* ---- the Pareto sweep over the NPI-cost weights as ONE call (Tools/TrainPredictPrescribeNPI.m:421-493, 624-633) ----
+ * The reference walks `for ll = 1 : num_pareto_front_points` (:421): SIAlphaModelEKFOptControlled with
+ * params.epsilon = human_npi_cost_factor(ll) (:460), SIalpha_Controlled over the horizon under opt_control_input_smooth from
+ * the end-of-history state (:481), NPICost over [historic, horizon] (:493); after the loop the non-dominated points and
+ * I_opt (:624-633).  epi_sweep_run_device is epi_ekf_run_device (same descriptor, inputs, outputs, workspace; model
+ * EPI_MODEL_SIA6, phase ignored = full call, fp64 u_opt_smooth selected) followed by epi_sialpha_score_device on the last
+ * T - t_hist days of the u_opt_smooth it wrote and, when on_front / i_opt are given, epi_pareto_front_device -- enqueued so
+ * that scoring and filter run BESIDE the smoother's pass over the observed days (the horizon's u_opt_smooth is final after
+ * the smoother's first T - 1 - t_hist steps; packed kernels, path_hint = 1; otherwise they follow it).  Results are
+ * bit-identical to the three separate calls.
+ *   sp [EPI_SIM_PRM_COUNT][B], J0_prefix / J1_prefix [B]: as for epi_sialpha_score_device (EPI_SIM_S0.. = s/i/alpha_historic
+ *   (end), prefix_days = t_hist);  J0, J1 [B];  on_front [R][P] / i_opt [R] or NULL (both NULL: no filter -- a shard of the
+ *   sweep that does not hold whole regions; then R, P are ignored). */
+typedef struct epi_sweep_desc {
+    int32_t abi_version;
+    int32_t R;        /* regions of this call */
+    int32_t P;        /* cost weights per region: chain c = region * P + ll, B == R * P */
+    int32_t t_hist;   /* NumNPIdays: observed days; the T - t_hist days after them are the horizon, 1 <= t_hist < T */
+} epi_sweep_desc;
+int epi_sweep_run_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, void *workspace,
+                         size_t workspace_bytes, const epi_sweep_desc *sd, const double *sp, const double *J0_prefix,
+                         const double *J1_prefix, double *J0, double *J1, int32_t *on_front, int32_t *i_opt, void *stream,
+                         char *err);
+
+/* The same from HOST pointers and PER-REGION inputs, for all regions at once and on several GPUs (what a MEX gateway
+ * binds: matlab/epiekf_pipeline_mex.cpp; replaces the two loops Tools/TrainPredictPrescribeNPI.m:93 and :421 around the
+ * 6-state filter).  The host sends R columns (a few hundred KB), the device expands them to the R * P chains, runs
+ * filter -> scoring -> front filter, and returns (J0, J1) per chain, the front, I_opt and the optimum's plan per region --
+ * a few MB instead of the 5.6 - 49 GB of per-chain filter outputs.  Regions are cut into n_devices contiguous blocks (whole
+ * regions, so the front filter needs no exchange); device_ids NULL = devices 0 .. n_devices-1.
+ * Inputs (host, region-minor: a MATLAB R x rows matrix is the [rows][R] array):
+ *   x [T][R], u [T][n_npi][R] (NaN over the horizon), R_series [T][R];
+ *   prm [EPI_PRM_COUNT][R] (row EPI_PRM_EPSILON is ignored), s_init [6][R], Ps_init [36][R], s_final [6][R],
+ *   Ps_final [36][R], Q [36][R];  eps [P] = human_npi_cost_factor;
+ *   sp [EPI_SIM_PRM_COUNT][R], J0_prefix / J1_prefix [R]  (scoring inputs, see epi_sialpha_score_device).
+ * Outputs (host; any may be NULL):
+ *   J0, J1 [R][P];  on_front [R][P];  i_opt [R] (0-based);
+ *   u_opt [T][n_npi][R] = u_opt_smooth of chain (r, i_opt[r]);  S_opt [T][6][R] = its S_SMOOTH;
+ *   extras: per-chain filter outputs selected by out_mask, classic layout [T][rows][R * P] (pinv_rank / status are not
+ *   returned); with out_mask != 0 the filter writes the classic layout and the call pays PCIe for what it selects. */
+typedef struct epi_prescribe_desc {
+    int32_t abi_version;
+    int32_t R, P;            /* regions, cost weights per region */
+    int32_t T, t_hist;       /* days incl. the horizon; observed days */
+    int32_t n_npi, L, order, obs_type;
+    uint32_t out_mask;       /* epi_out bits of the per-chain extras (0 = none) */
+    int32_t shape, time_pipe;/* as in epi_batch_desc (0 = let the library decide) */
+} epi_prescribe_desc;
+typedef struct epi_prescribe_inputs {
+    const double *x, *u, *R_series;
+    const double *prm, *s_init, *Ps_init, *s_final, *Ps_final, *Q;
+    const double *eps;
+    const double *sp, *J0_prefix, *J1_prefix;
+} epi_prescribe_inputs;
+typedef struct epi_prescribe_outputs {
+    double *J0, *J1;
+    int32_t *on_front, *i_opt;
+    double *u_opt, *S_opt;
+    epi_outputs extras;
+} epi_prescribe_outputs;
+int epi_sweep_prescribe_host(const epi_prescribe_desc *d, const epi_prescribe_inputs *in, const epi_prescribe_outputs *out,
+                             int n_devices, const int *device_ids, char *err);
 
 /* ---- Tools/Rt_ExpFitEKF.m:1 -- 2-state exponential-fit EKF/EKS over the new-case counts, order 1 or 2 ----
  * [S_MINUS, S_PLUS, P_MINUS, P_PLUS, K_GAIN, S_SMOOTH, P_SMOOTH, innovations, rho] =
@@ -370,6 +438,17 @@ typedef struct epi_nnls_desc {
 } epi_nnls_desc;
 int epi_nnls_affine_fit_device(const epi_nnls_desc *d, const double *X, const double *y, double *a, double *b,
                                double *min_err, int32_t *iters, int32_t *flag, void *stream, char *err);
+
+/* Host-pointer forms of the three stages around the filter (same arrays in host memory; staged through device `device`,
+ * synchronous): what matlab/epiekf_pipeline_mex.cpp binds for TrainPredictPrescribeNPI.m:142-198 (preprocessing),
+ * :251-276 (regression) and :496-521 (random-NPI Monte-Carlo). */
+int epi_preprocess_host(const epi_pre_desc *d, const double *cases, const double *deaths, const double *population,
+                        const double *ip, const epi_pre_outputs *out, int device, char *err);
+int epi_nnls_affine_fit_host(const epi_nnls_desc *d, const double *X, const double *y, double *a, double *b,
+                             double *min_err, int32_t *iters, int32_t *flag, int device, char *err);
+int epi_random_npi_mc_host(const epi_mc_desc *d, const double *sp, const double *u_min, const double *z,
+                           const double *J0_prefix, const double *J1_prefix, double *u_out, double *J0, double *J1,
+                           int device, char *err);
 
 /* SEIRP.m:1-32 / SEIRPSaturatedResource.m:1-38 batched: par [K][7][B] per-step parameter arrays in the
  * order alpha_e, alpha_i, kappa, rho, beta, mu, gamma (or constant-in-time: par [1][7][B], par_steps=1);

@@ -81,8 +81,10 @@ def test_validate_accepts_order_two_and_codegen_ignores_obs_type(hip_lib):
 
 def test_workspace_covers_unselected_forward_quantities(hip_lib):
     r256 = lambda n: (n + 255) // 256 * 256
-    # smoother intermediates every generic-model run needs: X = pinv(P_MINUS) [T][36][B], rank words, flag
+    # smoother intermediates every generic-model run needs: X = pinv(P_MINUS) [T][36][B], rank words, flag, and the
+    # hand-over rows between two backward launches (S_SMOOTH, P_SMOOTH, status word of one day)
     base = r256(4 * 10 * 8 * 21) + r256(4 * 10 * 4) + 256      # X is stored packed (21 of 36)
+    base += r256(4 * 8 * 6) + r256(4 * 8 * 36) + r256(4 * 4)
     full = hip_lib.epi_ekf_workspace_bytes(C.byref(_desc(model="SIAlphaModelEKFOptControlled")))
     assert full == base
     red = _desc(model="SIAlphaModelEKFOptControlled", out_mask=L.OUT_BITS["u_opt_smooth"] | L.OUT_BITS["S_SMOOTH"])

@@ -102,3 +102,43 @@ def test_shard_chains_covers_every_chain_once():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
             assert all(0 <= lo <= hi <= B for lo, hi in cuts)
     assert batch.shard_chains(75000, 7, 8) == (65625, 75000)
+
+
+def test_one_rank_world_still_issues_the_collective_gloo():
+    """batch.gather_to_root / gather_shards_to_root issue their collective for every world size (a one-rank world too:
+    the same code path as N ranks, which is what lets a one-GPU box execute the RCCL leg)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    sys.path.insert(0, H.ROOT)
+    from epidemicmodeling_amd import batch
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = []
+        orig = dist.gather
+        dist.gather = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            t = torch.arange(10, dtype=torch.float64).reshape(2, 5)
+            full = batch.gather_shards_to_root(t, 5)
+            parts = batch.gather_to_root(t)
+        finally:
+            dist.gather = orig
+        assert len(calls) == 2 and torch.equal(full, t) and len(parts) == 1 and torch.equal(parts[0], t)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_started_bare_launches_its_own_ranks_and_returns_their_failure():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (how the driver starts it) must start two ranks itself and hand back
+    their exit code.  Without a GPU every rank fails, so here: non-zero exit, no JSON line, and the failure text comes
+    from the child ranks (torch.distributed.run's report), not from an argument check in the parent."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: covered by tests/test_gpu_parity.py::test_bench_contract_single_and_two_ranks")
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--regions", "2",
+                        "--eps", "3", "--t-hist", "10", "--horizon", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=H.ROOT)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "must be launched with" not in r.stderr and ("ChildFailedError" in r.stderr or "rank" in r.stderr.lower()), r.stderr[-1500:]

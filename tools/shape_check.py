@@ -1,4 +1,4 @@
-"""Quick parity check of the three lane mappings and the launch modes against the oracle (GPU box; development aid):
+"""Quick parity check of the two lane mappings and the launch modes against the oracle (GPU box; development aid):
     PYTHONPATH=. python tools/shape_check.py"""
 import sys
 import numpy as np
@@ -14,16 +14,13 @@ def check(w, tag, **kw):
     return not bad
 
 ok = True
-for shape in ("pair", "quad", "lane"):
-    for chunks in (0, -3):
-        ok &= check(synth.make_cfg4(3, 7, 140, 12), "cfg4 small", shape=shape, chunks=chunks)
-        ok &= check(synth.make_cfg4(5, 13, 160, 20), "cfg4 blocked", shape=shape, chunks=chunks, lane_block="auto")
-        ok &= check(synth.as_backward(synth.make_cfg4(4, 5, 40, 0)), "sia6 backward", shape=shape, chunks=chunks)
-        ok &= check(synth.as_backward(synth.make_cfg3(6, 160)), "sia3 backward, long", shape=shape, chunks=chunks)
-        ok &= check(synth.make_cfg3(9, 150), "cfg3", shape=shape, chunks=chunks)
+for shape in ("quad", "lane"):
+    for tp in (0, 1, -1):
+        ok &= check(synth.make_cfg4(3, 7, 140, 12), "cfg4 small", shape=shape, time_pipe=tp)
+        ok &= check(synth.make_cfg4(5, 13, 160, 20), "cfg4 blocked", shape=shape, time_pipe=tp, lane_block="auto")
+        ok &= check(synth.as_backward(synth.make_cfg4(4, 5, 40, 0)), "sia6 backward", shape=shape, time_pipe=tp)
+        ok &= check(synth.as_backward(synth.make_cfg3(6, 160)), "sia3 backward, long", shape=shape, time_pipe=tp)
+        ok &= check(synth.make_cfg3(9, 150), "cfg3", shape=shape, time_pipe=tp)
 ok &= check(synth.make_row3(3, 6), "row3 adaptive R", shape="quad")
-ok &= check(synth.make_row3(3, 6), "row3 adaptive R (pair -> lane)", shape="pair")
-ok &= check(synth.make_cfg4(7, 30, 100, 30), "cfg4 210x130 pair classic", shape="pair", lane_block=0)
-ok &= check(synth.make_cfg4(7, 30, 100, 30), "cfg4 210x130 pair blk 5", shape="pair", lane_block=5)
 ok &= check(synth.make_cfg4(12, 50, 200, 60), "cfg4 600x260", shape="quad", lane_block="auto")
 sys.exit(0 if ok else 1)
