@@ -599,28 +599,30 @@ EPI_DEV int sym_pinv_two_sided(const double (&A)[M * M], double (&X)[M * M], boo
 //   2. one-sided Jacobi rotations orthogonalise the columns of G: the non-zero eigenvalues are the squared column norms,
 //      the eigenvectors the normalised columns; no eigenvector matrix is accumulated, 2 - 3.5 sweeps.
 //   3. X = sum over the kept columns of g g' / (g'g)^2.
-// Operation for operation the oracle's orc_sym_pinv; a lane whose matrix is not positive semi-definite up to rounding takes
-// sym_pinv_two_sided (the whole wavefront runs it then, the other lanes keep their result).  Every loop is wave-uniform:
+// Operation for operation the oracle's orc_sym_pinv; a lane whose matrix is not positive semi-definite up to rounding is
+// flagged and takes sym_pinv_two_sided in the caller (eks_pinv re-reads the matrix for it: rare).  Every loop is wave-uniform:
 // a pair / a factorisation step is skipped only if NO lane needs it, lanes that do not rotate apply the identity.
 constexpr int kPinvMaxSweeps = 30;
-template <int M, int BZS = 0>
-EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped, double *bz = nullptr)
+// Au: upper triangle of A, packed (entry (i, j), i <= j, at i + j (j + 1) / 2); Xu: upper triangle of X, packed the same way.
+// Returns the rank kept; *indef: this lane's matrix is not positive semi-definite up to rounding and Xu / the rank are NOT
+// valid -- the caller runs sym_pinv_two_sided for it.
+template <int M>
+EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (M + 1) / 2], bool *capped, bool *indef_out)
 {
     constexpr int NS = M * (M + 1) / 2;
     auto sx = [](int i, int j) constexpr { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; };
     double amax = 0.0;
 #pragma unroll
-    for (int i = 0; i < M * M; i++) amax = fmax(amax, fabs(A[i]));
+    for (int i = 0; i < NS; i++) amax = fmax(amax, fabs(Au[i]));
 #pragma unroll
-    for (int i = 0; i < M * M; i++) X[i] = 0.0;
+    for (int i = 0; i < NS; i++) Xu[i] = 0.0;
     *capped = false;
+    *indef_out = false;
     if (amax == 0.0) return 0;
     const int e = ilogb(amax);
-    double a[NS];                        // upper triangle, packed
+    double a[NS];
 #pragma unroll
-    for (int j = 0; j < M; j++)
-#pragma unroll
-        for (int i = 0; i <= j; i++) a[sx(i, j)] = ldexp(A[IXM(i, j)], -e);
+    for (int i = 0; i < NS; i++) a[i] = ldexp(Au[i], -e);
     double dmax0 = 0.0;
 #pragma unroll
     for (int i = 0; i < M; i++) dmax0 = fmax(dmax0, a[sx(i, i)]);
@@ -647,20 +649,41 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped,
             p = take ? i : p;
             d = take ? a[sx(i, i)] : d;
         }
-        // its column a(:, p)
+        // its column a(:, p).  The 64 same-day matrices of a wavefront nearly always pick the same pivot: then the column
+        // is named at compile time (six register copies); otherwise it is selected entry by entry.
         double colraw[M];
+        const int p0 = __builtin_amdgcn_readfirstlane(p);
+        if (__builtin_amdgcn_ballot_w64(active && p != p0) == 0ull) {
+            bool hit = false;
 #pragma unroll
-        for (int i = 0; i < M; i++) {
-            double v = a[sx(i, 0)];
+            for (int q = 0; q < M; q++)
+                if (!hit && p0 == q) {
+                    hit = true;
 #pragma unroll
-            for (int q = 1; q < M; q++) v = (p == q) ? a[sx(i, q)] : v;
-            colraw[i] = v;
+                    for (int i = 0; i < M; i++) colraw[i] = a[sx(i, q)];
+                }
+            if (!hit) {
+#pragma unroll
+                for (int i = 0; i < M; i++) colraw[i] = 0.0;      // no lane is active with p0 < 0
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double v = a[sx(i, 0)];
+#pragma unroll
+                for (int q = 1; q < M; q++) v = (p == q) ? a[sx(i, q)] : v;
+                colraw[i] = v;
+            }
         }
         bool quit = !(d * (double)(M - k) > stop);
+        if (__builtin_amdgcn_ballot_w64(active && d <= noise) != 0ull) {    // only pivots at the noise scale can be noise
+            bool viol = false;
 #pragma unroll
-        for (int i = 0; i < M; i++) {
-            const bool other = !((used >> i) & 1u) && i != p;
-            quit = quit || (other && (colraw[i] * colraw[i] > (4.0 * d) * fabs(a[sx(i, i)])));
+            for (int i = 0; i < M; i++) {
+                const bool other = !((used >> i) & 1u) && i != p;
+                viol = viol || (other && (colraw[i] * colraw[i] > (4.0 * d) * fabs(a[sx(i, i)])));
+            }
+            quit = quit || (d <= noise && viol);
         }
         if (__builtin_amdgcn_ballot_w64(active && quit) != 0ull) {
             double rest = 0.0;
@@ -674,7 +697,6 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped,
             indef = indef || (active && quit && rest > 0.25 * noise);
         }
         const bool go = active && !quit;
-        active = go;
         const double l = sqrt(d), il = 1.0 / l;
         double col[M];
 #pragma unroll
@@ -684,22 +706,29 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped,
             G[IXM(i, k)] = go ? col[i] : 0.0;
         }
         used = go ? (used | (1u << (p & 31))) : used;
-        // Schur complement of the free part (entries of used rows are never read again: they may take any value)
+        // Schur complement of the free part.  (Entries of used rows are never read again, and neither is anything of a
+        // lane that has stopped: both may take any value, so the update is not predicated.)
 #pragma unroll
         for (int j = 0; j < M; j++)
 #pragma unroll
-            for (int i = 0; i <= j; i++) {
-                const double upd = fma(-col[i], col[j], a[sx(i, j)]);
-                a[sx(i, j)] = go ? upd : a[sx(i, j)];
-            }
+            for (int i = 0; i <= j; i++) a[sx(i, j)] = fma(-col[i], col[j], a[sx(i, j)]);
         bool negd = false;
 #pragma unroll
         for (int i = 0; i < M; i++) negd = negd || (!((used >> i) & 1u) && a[sx(i, i)] < -0.25 * noise);
         indef = indef || (go && negd);
-        active = active && !negd;
+        active = go && !negd;
         r = go ? k + 1 : r;
     }
-    // one-sided Jacobi on the r columns of G
+    // one-sided Jacobi on the r columns of G.  The squared column norms are kept beside G and formed anew (same fma chain
+    // the oracle runs at every test) for the two columns a rotation has touched.
+    double nrm[M];
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; i++) s2 = fma(G[IXM(i, k)], G[IXM(i, k)], s2);
+        nrm[k] = s2;
+    }
     bool done = indef || r < 2;
     bool cap = false;
     for (int sweep = 1; sweep <= kPinvMaxSweeps; sweep++) {
@@ -711,27 +740,34 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped,
             for (int q = p + 1; q < M; q++) {
                 const bool in = !done && q < r;
                 if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;
-                double al = 0.0, be = 0.0, ga = 0.0;
+                const double al = nrm[p], be = nrm[q];
+                double ga = 0.0;
 #pragma unroll
-                for (int i = 0; i < M; i++) {
-                    al = fma(G[IXM(i, p)], G[IXM(i, p)], al);
-                    be = fma(G[IXM(i, q)], G[IXM(i, q)], be);
-                    ga = fma(G[IXM(i, p)], G[IXM(i, q)], ga);
-                }
+                for (int i = 0; i < M; i++) ga = fma(G[IXM(i, p)], G[IXM(i, q)], ga);
                 const bool rot = in && (ga * ga > 0x1p-106 * (al * be));
                 if (__builtin_amdgcn_ballot_w64(rot) == 0ull) continue;
                 rotated = rotated || rot;
+                // cos = (|h| + w) / D, sin = 2 ga / D, D = sqrt(2 w (|h| + w)) (see the oracle); the identity (cos = 1,
+                // sin = 0) for the lanes that do not rotate
                 const double h = be - al, two = 2.0 * ga;
-                double t = two / (fabs(h) + sqrt(fma(h, h, two * two)));
-                t = (h < 0.0) ? -t : t;
-                t = rot ? t : 0.0;                     // identity for the lanes that do not rotate: c = 1, s = 0
-                const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = t * c;
+                const double w = sqrt(fma(h, h, two * two)), sum = fabs(h) + w;
+                const double iD = 1.0 / sqrt((2.0 * w) * sum);
+                const double c = rot ? sum * iD : 1.0;
+                double s = two * iD;
+                s = (h < 0.0) ? -s : s;
+                s = rot ? s : 0.0;
+                double np = 0.0, nq = 0.0;
 #pragma unroll
                 for (int i = 0; i < M; i++) {
                     const double gp = G[IXM(i, p)], gq = G[IXM(i, q)];
-                    G[IXM(i, p)] = fma(c, gp, -(s * gq));
-                    G[IXM(i, q)] = fma(s, gp, c * gq);
+                    const double xp = fma(c, gp, -(s * gq)), xq = fma(s, gp, c * gq);
+                    G[IXM(i, p)] = xp;
+                    G[IXM(i, q)] = xq;
+                    np = fma(xp, xp, np);
+                    nq = fma(xq, xq, nq);
                 }
+                nrm[p] = np;
+                nrm[q] = nq;
             }
         }
         cap = cap || (!done && rotated && sweep == kPinvMaxSweeps);
@@ -740,10 +776,7 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped,
     double lam[M], lmax = 0.0;
 #pragma unroll
     for (int k = 0; k < M; k++) {
-        double s2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < M; i++) s2 = fma(G[IXM(i, k)], G[IXM(i, k)], s2);
-        lam[k] = (k < r) ? s2 : 0.0;
+        lam[k] = (k < r) ? nrm[k] : 0.0;
         lmax = fmax(lmax, lam[k]);
     }
     const double tol = (double)M * eps_of(lmax);
@@ -754,31 +787,16 @@ EPI_DEV int sym_pinv(const double (&A)[M * M], double (&X)[M * M], bool *capped,
         if (__builtin_amdgcn_ballot_w64(keep) == 0ull) continue;
         rank += keep ? 1 : 0;
         const double w = keep ? 1.0 / (lam[k] * lam[k]) : 0.0;
+        // (w = 0 for the lanes that do not keep column k: G w = 0 and fma(0, g, x) = x, finite operands)
 #pragma unroll
         for (int c = 0; c < M; c++)
 #pragma unroll
-            for (int rr = 0; rr <= c; rr++) {
-                const double acc = fma(G[IXM(rr, k)] * w, G[IXM(c, k)], X[IXM(rr, c)]);
-                X[IXM(rr, c)] = keep ? acc : X[IXM(rr, c)];
-            }
+            for (int rr = 0; rr <= c; rr++) Xu[sx(rr, c)] = fma(G[IXM(rr, k)] * w, G[IXM(c, k)], Xu[sx(rr, c)]);
     }
 #pragma unroll
-    for (int c = 0; c < M; c++)
-#pragma unroll
-        for (int rr = 0; rr <= c; rr++) {
-            X[IXM(rr, c)] = ldexp(X[IXM(rr, c)], -e);
-            X[IXM(c, rr)] = X[IXM(rr, c)];
-        }
+    for (int i = 0; i < NS; i++) Xu[i] = ldexp(Xu[i], -e);
     *capped = cap;
-    if (__builtin_amdgcn_ballot_w64(indef) != 0ull) {      // rare: not positive semi-definite up to rounding
-        double X2[M * M];
-        bool cap2;
-        const int rank2 = sym_pinv_two_sided<M, BZS>(A, X2, &cap2, bz);
-#pragma unroll
-        for (int i = 0; i < M * M; i++) X[i] = indef ? X2[i] : X[i];
-        rank = indef ? rank2 : rank;
-        *capped = indef ? cap2 : cap;
-    }
+    *indef_out = indef;
     return rank;
 }
 

@@ -438,46 +438,57 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)blockIdx.y;
     const int c = a.c0 + cl;
     const Lay lay = make_lay(a, c);
-    double P[M * M];
-    // P_MINUS is stored symmetrised (:161): read the upper triangle only and mirror it
-    {
-        unsigned voff, rowb;
-        const rsrc_t r = lay_slice(a.P_MINUS, t1, M * M, lay, voff, rowb);
-#pragma unroll
-        for (int j = 0; j < M; j++)
-#pragma unroll
-            for (int i = 0; i <= j; i++) {
-                const double v = bld(r, voff, (unsigned)IXM(i, j) * rowb);
-                P[IXM(i, j)] = v;
-                P[IXM(j, i)] = v;
-            }
-    }
-    bool bad = false;                                      // :211
+    constexpr int NSX = M * (M + 1) / 2;
+    double Pu[NSX];
+    // P_MINUS is stored symmetrised (:161): only its upper triangle is read
+    unsigned voff_p, rowb_p;
+    const rsrc_t rp = lay_slice(a.P_MINUS, t1, M * M, lay, voff_p, rowb_p);
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) bad = bad || is_nonfinite(P[IXM(i, j)]);
+        for (int i = 0; i <= j; i++) Pu[i + j * (j + 1) / 2] = bld(rp, voff_p, (unsigned)IXM(i, j) * rowb_p);
+    bool bad = false;                                      // :211
+#pragma unroll
+    for (int i = 0; i < NSX; i++) bad = bad || is_nonfinite(Pu[i]);
     int32_t *rword = a.rankbuf + lay_scalar(t1, lay);
     if (bad) {
         *rword = -1;
         return;
     }
-    double X[M * M];
-    bool capped;
-    // 6 x 6: the Jacobi's b/z accumulators in LDS (one column per lane), see jacobi_eig
-    constexpr int BZS = (M >= 6) ? pinv_wg<M>() : 0;
-    __shared__ double bzs[BZS ? 2 * M * BZS : 1];
-    const int rank = sym_pinv<M, BZS>(P, X, &capped, bzs + threadIdx.x);           // :215
-    {   // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
-        constexpr int NSX = M * (M + 1) / 2;
-        unsigned voff, rowb;
-        const rsrc_t r = lay_slice(a.X, t1, NSX, lay, voff, rowb);
+    // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
+    double Xu[NSX];
+    bool capped, indef;
+    int rank = sym_pinv_psd<M>(Pu, Xu, &capped, &indef);              // :215
+    unsigned voff_x, rowb_x;
+    const rsrc_t rx = lay_slice(a.X, t1, NSX, lay, voff_x, rowb_x);
+#pragma unroll
+    for (int i = 0; i < NSX; i++) bst(rx, voff_x, (unsigned)i * rowb_x, Xu[i]);
+    *rword = rank | (capped ? 0x100 : 0);
+    if (__builtin_amdgcn_ballot_w64(indef) != 0ull) {
+        // Not positive semi-definite up to rounding (never the case for a covariance the filter produced from a positive
+        // semi-definite Ps_init): the two-sided Jacobi route on the matrix read again; the lanes concerned overwrite what
+        // they stored above (nothing of the first route is live across this block).
+        constexpr int BZS = (M >= 6) ? pinv_wg<M>() : 0;
+        __shared__ double bzs[BZS ? 2 * M * BZS : 1];      // its b/z accumulators (one column per lane), see jacobi_eig
+        double P[M * M], X[M * M];
 #pragma unroll
         for (int j = 0; j < M; j++)
 #pragma unroll
-            for (int i = 0; i <= j; i++) bst(r, voff, (unsigned)(i + j * (j + 1) / 2) * rowb, X[IXM(i, j)]);
+            for (int i = 0; i <= j; i++) {
+                const double v = bld(rp, voff_p, (unsigned)IXM(i, j) * rowb_p);
+                P[IXM(i, j)] = v;
+                P[IXM(j, i)] = v;
+            }
+        bool capped2;
+        const int rank2 = sym_pinv_two_sided<M, BZS>(P, X, &capped2, bzs + threadIdx.x);
+        if (indef) {
+#pragma unroll
+            for (int j = 0; j < M; j++)
+#pragma unroll
+                for (int i = 0; i <= j; i++) bst(rx, voff_x, (unsigned)(i + j * (j + 1) / 2) * rowb_x, X[IXM(i, j)]);
+            *rword = rank2 | (capped2 ? 0x100 : 0);
+        }
     }
-    *rword = rank | (capped ? 0x100 : 0);
 }
 
 // ---------------------------------------------------------------------------

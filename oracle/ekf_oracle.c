@@ -283,7 +283,7 @@ static int sym_pinv_two_sided(int m, const double *A, double *X)
  *      is SELECTED, rows stay where they are: column k of G belongs to the k-th pivot).  It ends when the trace of what is
  *      left, an upper bound of its eigenvalues, is below 2^-20 of MATLAB's cut-off (so dropping S moves the kept eigenvalues
  *      by < 1e-6 of the SMALLEST value the rule can keep), or when the pivot column violates a_ip^2 <= a_pp a_ii beyond
- *      rounding, i.e. when rounding noise has taken over.  For the filter's covariances 45 % of the singular values fall
+ *      rounding (tested for pivots at or below the cut-off's scale), i.e. when rounding noise has taken over.  For the filter's covariances 45 % of the singular values fall
  *      under the cut-off: G then has 2 or 3 columns instead of 6.
  *   2. one-sided Jacobi (Hestenes) rotations make the columns of G orthogonal; A's non-zero eigenvalues are then the
  *      squared column norms, its eigenvectors the normalised columns -- no eigenvector matrix is accumulated, and
@@ -319,11 +319,12 @@ int orc_sym_pinv(int m, const double *A, double *X)
         for (int i = 0; i < m; i++)
             if (!used[i] && (p < 0 || a[IX(i, i, m)] > d)) { p = i; d = a[IX(i, i, m)]; }
         int quit = !(d * (double)(m - k) > stop);
-        for (int i = 0; i < m; i++)
-            if (!used[i] && i != p) {
-                const double x = a[IX(i < p ? i : p, i < p ? p : i, m)];
-                quit |= (x * x > (4.0 * d) * fabs(a[IX(i, i, m)]));
-            }
+        if (d <= noise)     /* (a pivot above the noise scale cannot be rounding noise: the test is not needed there) */
+            for (int i = 0; i < m; i++)
+                if (!used[i] && i != p) {
+                    const double x = a[IX(i < p ? i : p, i < p ? p : i, m)];
+                    quit |= (x * x > (4.0 * d) * fabs(a[IX(i, i, m)]));
+                }
         if (quit) {
             double rest = 0.0;
             for (int j = 0; j < m; j++)
@@ -357,11 +358,15 @@ int orc_sym_pinv(int m, const double *A, double *X)
                 }
                 if (!(ga * ga > 0x1p-106 * (al * be))) continue;   /* orthogonal to working precision */
                 rotated = 1;
-                /* t = sgn(zeta)/(|zeta| + sqrt(zeta^2+1)), zeta = (be - al)/(2 ga), multiplied through by |2 ga| */
+                /* tan = sgn(zeta)/(|zeta| + sqrt(zeta^2+1)), zeta = (be - al)/(2 ga); multiplied through by |2 ga|:
+                 * tan = 2 ga / (|h| + w), h = be - al, w = sqrt(h^2 + (2 ga)^2), and 1 + tan^2 = 2 w (|h| + w) / (|h| + w)^2,
+                 * so cos = (|h| + w) / D and sin = 2 ga / D with D = sqrt(2 w (|h| + w)): two square roots, ONE division */
                 const double h = be - al, two = 2.0 * ga;
-                double t = two / (fabs(h) + sqrt(fma(h, h, two * two)));
-                if (h < 0.0) t = -t;
-                const double c = 1.0 / sqrt(fma(t, t, 1.0)), s = t * c;
+                const double w = sqrt(fma(h, h, two * two)), sum = fabs(h) + w;
+                const double iD = 1.0 / sqrt((2.0 * w) * sum);
+                const double c = sum * iD;
+                double s = two * iD;
+                if (h < 0.0) s = -s;
                 for (int i = 0; i < m; i++) {
                     const double gp = G[IX(i, p, m)], gq = G[IX(i, q, m)];
                     G[IX(i, p, m)] = fma(c, gp, -(s * gq));
