@@ -35,3 +35,60 @@ extern "C" int run_probe(double *out, int B, int T, int rows, int blk, int mode,
     hipLaunchKernelGGL(probe, dim3((B + blk - 1) / blk), dim3(64), 0, (hipStream_t)stream, out, B, T, rows, blk, mode, work, lb);
     return (int)hipGetLastError();
 }
+
+// Round 3: the smoother's side.  eks_bwd_sym reads ~76 doubles per chain and step (S+ 6, P+ 21, S- 6, P- 21, X 21, rank word)
+// and writes 54 (S_SMOOTH 6, P_SMOOTH 36, u_opt_smooth 12) as one lone 370-VGPR wave per SIMD.  Would 16 B per lane on
+// the reads (row PAIRS interleaved per chain, buffer_load_b128) move the 24.5 GB faster than 8 B per lane?
+//   rmode / wmode 0: [t][B/blk][row][blk] 8 B per lane      1: [t][B/blk][row/2][blk][2] 16 B per lane
+// `work` FMAs in four independent chains sit between a step's loads and its stores; 40 KB of LDS per workgroup keeps the
+// occupancy at one wave per SIMD like the real kernel.
+extern "C" __global__ __launch_bounds__(64) void probe_rw(const double *in, double *out, int B, int T, int rrows, int wrows, int blk,
+                                                           int rmode, int wmode, int work)
+{
+    extern __shared__ double pad[];
+    const int lane = threadIdx.x, c = blockIdx.x * blk + lane;
+    if (lane >= blk || c >= B) return;
+    if (work < 0) pad[lane] = 1.0;
+    double acc0 = 0.0, acc1 = 1.0, acc2 = 2.0, acc3 = 3.0;
+    for (int t = T - 1; t >= 0; t--) {
+        const size_t slice = (size_t)t * gridDim.x + blockIdx.x;
+        // every load of the step is issued before the first one is consumed (as the real kernel does): 76 rows in flight
+        constexpr int RR = 76;
+        double s = 0.0;
+        if (rmode == 0) {
+            const double *p = in + slice * RR * blk + lane;
+            double v[RR];
+#pragma unroll
+            for (int r = 0; r < RR; r++) v[r] = p[(size_t)r * blk];
+#pragma unroll
+            for (int r = 0; r < RR; r++) s += v[r];
+        } else {
+            const double2 *p = (const double2 *)in + slice * (RR / 2) * blk + lane;
+            double2 v[RR / 2];
+#pragma unroll
+            for (int r = 0; r < RR / 2; r++) v[r] = p[(size_t)r * blk];
+#pragma unroll
+            for (int r = 0; r < RR / 2; r++) s += v[r].x + v[r].y;
+        }
+        acc0 += s;
+        for (int w = 0; w < work; w += 4) {
+            acc0 = fma(acc0, 1.0000001, 1e-12); acc1 = fma(acc1, 1.0000001, 1e-12);
+            acc2 = fma(acc2, 1.0000001, 1e-12); acc3 = fma(acc3, 1.0000001, 1e-12);
+        }
+        const double v = (acc0 + acc1) + (acc2 + acc3);
+        if (wmode == 0) {
+            double *p = out + slice * wrows * blk + lane;
+            for (int r = 0; r < wrows; r++) p[(size_t)r * blk] = v + r;
+        } else {
+            double2 *p = (double2 *)out + slice * (wrows / 2) * blk + lane;
+            for (int r = 0; r < wrows / 2; r++) p[(size_t)r * blk] = make_double2(v + r, v - r);
+        }
+    }
+}
+extern "C" int run_probe_rw(const double *in, double *out, int B, int T, int rrows, int wrows, int blk, int rmode, int wmode, int work,
+                            void *stream)
+{
+    hipLaunchKernelGGL(probe_rw, dim3((B + blk - 1) / blk), dim3(64), 40 * 1024, (hipStream_t)stream, in, out, B, T, rrows, wrows, blk,
+                       rmode, wmode, work);
+    return (int)hipGetLastError();
+}
