@@ -54,34 +54,58 @@ def workload3(x, R, u, N, I0, a, b):
                           Ps_final=np.full((9, S), np.nan), Q=Q)
 
 
+def sweep_region_inputs(N, I0, a, b, n, w_eff=1.0):
+    """Per-REGION arguments of the 6-state sweep (TrainPredictPrescribeNPI.m:423-453): prm [61,S] (EPSILON row left 0),
+    s_init [6,S], Ps_init, s_final, Ps_final, Q [36,S].  The cost weight is the only thing that differs between the P
+    chains of a region."""
+    S = N.shape[0]
+    s3, Q3, P3 = filter_setup(I0, N)
+    prm = _prm3(N, a, b, n)
+    prm[L.PRM_W_EFF:L.PRM_W_EFF + n] = w_eff
+    s_init = np.zeros((6, S)); s_init[:3] = s3
+    Q = np.zeros((36, S)); P0 = np.zeros((36, S))
+    for d in range(3):
+        Q[d * 6 + d] = Q3[d * 3 + d]; P0[d * 6 + d] = P3[d * 3 + d]
+    for d in range(3, 6):
+        Q[d * 6 + d] = synth.Q_LAMBDA ** 2; P0[d * 6 + d] = 10.0 * synth.Q_LAMBDA ** 2
+    s_final = np.full((6, S), np.nan); s_final[3:] = 0.0
+    Ps_final = np.zeros((36, S))
+    for i in range(3):
+        for j in range(3):
+            Ps_final[i + 6 * j] = np.nan
+    for d in range(3, 6):
+        Ps_final[d * 6 + d] = 1e-8
+    return dict(prm=prm, s_init=s_init, Ps_init=P0, s_final=s_final, Ps_final=Ps_final, Q=Q)
+
+
 def workload6(x, R, u, N, I0, a, b, eps_grid, w_eff=1.0):
     """SIAlphaModelEKFOptControlled sweep: chain c = region * n_eps + e (:421-460).  x, R [T,S] with NaN over the
     horizon, u [T,n,S] with NaN over the horizon."""
     T, S = x.shape
     n, P = u.shape[1], eps_grid.shape[0]
     rr = np.repeat(np.arange(S), P)
-    s3, Q3, P3 = filter_setup(I0, N)
-    prm = _prm3(N, a, b, n)[:, rr]
+    reg = sweep_region_inputs(N, I0, a, b, n, w_eff)
+    prm = reg["prm"][:, rr]
     prm[L.PRM_EPSILON] = np.tile(eps_grid, S)
-    prm[L.PRM_W_EFF:L.PRM_W_EFF + n] = w_eff
-    B = S * P
-    s_init = np.zeros((6, B)); s_init[:3] = s3[:, rr]
-    Q = np.zeros((36, B)); P0 = np.zeros((36, B))
-    for d in range(3):
-        Q[d * 6 + d] = Q3[d * 3 + d][rr]; P0[d * 6 + d] = P3[d * 3 + d][rr]
-    for d in range(3, 6):
-        Q[d * 6 + d] = synth.Q_LAMBDA ** 2; P0[d * 6 + d] = 10.0 * synth.Q_LAMBDA ** 2
-    s_final = np.full((6, B), np.nan); s_final[3:] = 0.0
-    Ps_final = np.zeros((36, B))
-    for i in range(3):
-        for j in range(3):
-            Ps_final[i + 6 * j] = np.nan
-    for d in range(3, 6):
-        Ps_final[d * 6 + d] = 1e-8
     return synth.Workload(model="SIAlphaModelEKFOptControlled", T=T, n_npi=n, x=np.ascontiguousarray(x),
                           u=np.ascontiguousarray(u), R_series=np.ascontiguousarray(R), R_scalar=None,
-                          x_series=rr.astype(np.int32), u_series=rr.astype(np.int32), prm=prm, s_init=s_init, Ps_init=P0,
-                          s_final=s_final, Ps_final=Ps_final, Q=Q)
+                          x_series=rr.astype(np.int32), u_series=rr.astype(np.int32), prm=prm, s_init=reg["s_init"][:, rr],
+                          Ps_init=reg["Ps_init"][:, rr], s_final=reg["s_final"][:, rr], Ps_final=reg["Ps_final"][:, rr],
+                          Q=reg["Q"][:, rr])
+
+
+def scoring_region_inputs(hist_end, a, b, u_max, wts):
+    """Per-region scoring block sp [48,S] (EPI_SIM_* rows) of the sweep's tail (:481): end-of-history state, model
+    constants, NPI_MAXES, NPICost weights."""
+    n, S = a.shape
+    sp = np.zeros((batch.SIM_PRM_COUNT, S))
+    sp[0:3] = hist_end
+    sp[3], sp[4], sp[5] = synth.ALPHA_MIN, synth.ALPHA_MAX, synth.MODEL_GAMMA
+    sp[6], sp[7], sp[11] = b, synth.MODEL_BETA, 1.0
+    sp[batch.SIM_A:batch.SIM_A + n] = a
+    sp[batch.SIM_U_MAX:batch.SIM_U_MAX + n] = u_max[:, None]
+    sp[batch.SIM_W:batch.SIM_W + n] = wts
+    return sp
 
 
 def _alpha_smooth(w, device):
@@ -133,15 +157,13 @@ def prescribe(cases, deaths, population, ip, horizon=30, n_eps=50, num_regressio
     # scoring (:481-493): simulate the horizon from the end-of-history state, NPICost over [historic, horizon]
     wts = np.ones((n, S)) if npi_weights is None else np.asarray(npi_weights, dtype=np.float64)
     rr = np.repeat(np.arange(S), n_eps)
-    sp = np.zeros((batch.SIM_PRM_COUNT, S * n_eps))
-    sp[0:3] = hist[T - 1][:, rr]
-    sp[3], sp[4], sp[5] = synth.ALPHA_MIN, synth.ALPHA_MAX, synth.MODEL_GAMMA
-    sp[6], sp[7], sp[11] = fit2["b"][rr], synth.MODEL_BETA, 1.0
-    sp[batch.SIM_A:batch.SIM_A + n] = fit2["a"][:, rr]
-    sp[batch.SIM_U_MAX:batch.SIM_U_MAX + n] = u_max[:, None]
-    sp[batch.SIM_W:batch.SIM_W + n] = wts[:, rr]
-    J0p = np.cumsum(hist[:, 0] * hist[:, 1] * hist[:, 2], axis=0)[-1][rr]              # sequential historic sums
-    J1p = np.cumsum((wts[None] * u).reshape(T * n, S), axis=0)[-1][rr]
+    sp_region = scoring_region_inputs(hist[T - 1], fit2["a"], fit2["b"], u_max, wts)
+    sp = sp_region[:, rr]
+    J0p_region = np.cumsum(hist[:, 0] * hist[:, 1] * hist[:, 2], axis=0)[-1]           # sequential historic sums
+    J1p_region = np.cumsum((wts[None] * u).reshape(T * n, S), axis=0)[-1]
+    J0p, J1p = J0p_region[rr], J1p_region[rr]
+    out.update(sp_region=sp_region, J0_prefix_region=J0p_region, J1_prefix_region=J1p_region, x_sweep=xh, R_sweep=Rh, u_sweep=u_nan,
+               sweep_region=sweep_region_inputs(N, I0, fit2["a"], fit2["b"], n), I0=I0, u_fixed=u_fixed, X_reg=X)
     sc = batch.score_sweep(uos, T, sp, J0p, J1p, B=S * n_eps)
     front, i_opt = batch.pareto_front(sc["J0"], sc["J1"], S)
     torch.cuda.synchronize(dw.device)

@@ -29,6 +29,7 @@ static const int32_t *series_or_null(const mxArray *a, mwSize B, const char *nam
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    mexAtExit(epi_host_pool_release);       // `clear mex` hands the library's pooled host contexts and helper streams back
     if (nrhs != 15) mexErrMsgTxt("epiekf_batch_mex: 15 inputs expected");
     const int model = (int)mxGetScalar(prhs[0]);
     const int m = epi_model_dim(model);

@@ -21,6 +21,7 @@ static void fail(int rc, const char *err)
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    mexAtExit(epi_host_pool_release);       // `clear mex` hands the library's pooled host contexts and helper streams back
     if (nrhs != 13) mexErrMsgTxt("epiekf_mex: 13 inputs expected");
     const int model = (int)mxGetScalar(prhs[0]);
     const int m = epi_model_dim(model);

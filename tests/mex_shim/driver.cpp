@@ -1,6 +1,6 @@
 // driver.cpp -- calls the mexFunction of one of the gateways in matlab/ with arrays read from a file and writes what it
 // returned (tests/test_mex_boundary.py).  The gateways are compiled with -DmexFunction=mex_<name>.
-//   driver <epiekf|batch|rt|sim> <in.bin> <out.bin> <nlhs>
+//   driver <epiekf|batch|rt|sim|pipeline> <in.bin> <out.bin> <nlhs>
 // File format: int32 count, then per array { int32 class (6 double, 12 int32, 4 char), int32 ndim, int64 dims[ndim],
 // raw column-major data }.  A struct result is written field by field, in field order.
 #include "mex.h"
@@ -13,6 +13,7 @@ void mex_epiekf(int, mxArray *[], int, const mxArray *[]);
 void mex_batch(int, mxArray *[], int, const mxArray *[]);
 void mex_rt(int, mxArray *[], int, const mxArray *[]);
 void mex_sim(int, mxArray *[], int, const mxArray *[]);
+void mex_pipeline(int, mxArray *[], int, const mxArray *[]);
 }
 static size_t esz(int c) { return c == mxDOUBLE_CLASS ? 8 : c == mxINT32_CLASS ? 4 : 1; }
 static void write_array(FILE *f, const mxArray *a)
@@ -49,9 +50,11 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "batch")) mex_batch(nlhs, plhs, (int)prhs.size(), prhs.data());
         else if (!strcmp(argv[1], "rt")) mex_rt(nlhs, plhs, (int)prhs.size(), prhs.data());
         else if (!strcmp(argv[1], "sim")) mex_sim(nlhs, plhs, (int)prhs.size(), prhs.data());
+        else if (!strcmp(argv[1], "pipeline")) mex_pipeline(nlhs, plhs, (int)prhs.size(), prhs.data());
         else { fprintf(stderr, "unknown gateway\n"); return 2; }
     } catch (const MexError &e) {
         fprintf(stderr, "MEXERROR[%s]: %s\n", e.id.c_str(), e.msg.c_str());
+        mxShimRunAtExit();
         return 3;
     }
     FILE *o = fopen(argv[3], "wb");
@@ -66,5 +69,6 @@ int main(int argc, char **argv)
     fwrite(&n, 4, 1, o);
     for (const mxArray *a : res) write_array(o, a);
     fclose(o);
+    mxShimRunAtExit();        // what `clear mex` does: the gateways hand the library's pools and worker threads back
     return 0;
 }

@@ -36,6 +36,8 @@ int mxShimNumberOfFields(const mxArray *pa);
 mxArray *mxShimGetFieldByNumber(const mxArray *pa, int fieldnumber);
 const char *mxShimGetFieldName(const mxArray *pa, int fieldnumber);
 int mxShimClass(const mxArray *pa);
+int mexAtExit(void (*exit_fcn)(void));   /* registered functions run when the MEX file is cleared: the driver runs them at exit */
+void mxShimRunAtExit(void);
 void mexErrMsgTxt(const char *msg);
 void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...);
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);

@@ -95,6 +95,18 @@ int mxGetString(const mxArray *pa, char *str, mwSize len)
     str[k] = 0;
     return n > len - 1 ? 1 : 0;
 }
+static std::vector<void (*)(void)> g_at_exit;
+int mexAtExit(void (*exit_fcn)(void))
+{
+    for (auto f : g_at_exit) if (f == exit_fcn) return 0;       // MATLAB keeps one exit function per MEX file
+    g_at_exit.push_back(exit_fcn);
+    return 0;
+}
+void mxShimRunAtExit(void)
+{
+    for (auto f : g_at_exit) f();
+    g_at_exit.clear();
+}
 void mexErrMsgTxt(const char *msg) { throw MexError{"", msg}; }
 void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...)
 {

@@ -1,4 +1,4 @@
-"""The MATLAB-facing boundary, executed: the four MEX gateways of matlab/ are compiled against tests/mex_shim/mex.h (a small
+"""The MATLAB-facing boundary, executed: the five MEX gateways of matlab/ are compiled against tests/mex_shim/mex.h (a small
 IMPLEMENTED stand-in for the MEX / C Matrix API), linked with libepiekf.so and driven by tests/mex_shim/driver.cpp with
 MATLAB-shaped column-major arrays.  What is checked: shapes and order of the returned struct fields (the reference's output
 order, Tools/SIAlphaModelEKF.m:1), bit-for-bit equality with the CPU oracle, the reference's error texts, and -- without a
@@ -19,7 +19,8 @@ from tests import helpers as H
 
 SHIM = os.path.join(H.ROOT, "tests", "mex_shim")
 BUILD = os.path.join(SHIM, "build")
-GATEWAYS = {"epiekf": "epiekf_mex.cpp", "batch": "epiekf_batch_mex.cpp", "rt": "epiekf_rt_mex.cpp", "sim": "epiekf_sim_mex.cpp"}
+GATEWAYS = {"epiekf": "epiekf_mex.cpp", "batch": "epiekf_batch_mex.cpp", "rt": "epiekf_rt_mex.cpp", "sim": "epiekf_sim_mex.cpp",
+            "pipeline": "epiekf_pipeline_mex.cpp"}
 CLS = {np.dtype(np.float64): 6, np.dtype(np.int32): 12, np.dtype(np.uint8): 4}
 DT = {6: np.float64, 12: np.int32, 4: np.uint8}
 
@@ -236,3 +237,82 @@ def test_rt_and_simulator_gateways(gpu_device, driver):
     res = _call(driver, "sim", ["si", alpha.reshape(1, K), np.array([[0.05], [0.99], [0.01]]), float(K), 0.1], nlhs=2)
     assert np.array_equal(res[0], np.asarray(s2).reshape(1, K)) and np.array_equal(res[1], np.asarray(i2).reshape(1, K))
     _call(driver, "sim", ["nonsense"], expect_error="unknown command")
+
+
+def _batch3(driver, w, tmp=None):
+    """SIAlphaModelEKF for all regions of workload `w` through epiekf_batch_mex (region index first); returns S_SMOOTH [T, 3, S]."""
+    S, T = w.B, w.T
+    args = [0.0, np.transpose(w.u, (2, 1, 0)), w.x.T, w.prm.T, w.s_init.T, w.Ps_init.T, w.s_final.T, w.Ps_final.T, w.Q.T,
+            w.R_series.T, float(w.L), float(w.order), 0.0, np.zeros((0, 1), dtype=np.int32), np.zeros((0, 1), dtype=np.int32)]
+    res = _call(driver, "batch", args, tmp=tmp)
+    return np.transpose(res[ORDER11.index("S_SMOOTH")], (2, 1, 0))
+
+
+@pytest.mark.gpu
+def test_prescription_pipeline_through_the_gateways_only(gpu_device, driver, tmp_path):
+    """Tools/TrainPredictPrescribeNPI.m's device stages chained through the MEX gateways alone -- no Python device API in
+    the chain: preprocess -> SIAlphaModelEKF (zero input) -> regression -> SIAlphaModelEKF (real inputs) -> regression ->
+    forecast filter -> the cost-weight sweep of all regions with scoring and Pareto front in ONE call -> random-NPI
+    Monte-Carlo.  Every stage's result equals what epidemicmodeling_amd.pipeline.prescribe (the torch-side chain, itself
+    held to the oracle stage by stage in tests/test_gpu_parity.py) computes, bit for bit."""
+    from epidemicmodeling_amd import batch, pipeline
+    tmp = str(tmp_path)
+    S, T, n, H_, P = 5, 90, 12, 20, 30
+    d = synth.make_raw_counts(S, T, seed=11)
+    d["cases"][:, -1] = np.cumsum(np.full(T, 40.0))              # the all-NaN region of the generator: give it data
+    ref = pipeline.prescribe(d["cases"], d["deaths"], d["population"], d["ip"], horizon=H_, n_eps=P, num_regression_days=60,
+                             device=gpu_device)
+    N = np.asarray(d["population"], dtype=np.float64)
+    # 1. preprocessing
+    pre = _call(driver, "pipeline", ["preprocess", d["cases"].T, d["deaths"].T, N.reshape(S, 1), np.transpose(d["ip"], (2, 1, 0)), 7.0, 7.0,
+                                     float(synth.MIN_CASES)], tmp=tmp)
+    names = ["new_refined", "new_smoothed", "zero_lag", "x_new", "x_total", "R_v", "fatality", "I0", "ip_filled"]
+    pre = dict(zip(names, pre))
+    for k in names:
+        want = ref["pre"][k]
+        got = pre[k].T if pre[k].ndim == 2 and k != "I0" else (pre[k].reshape(-1) if k == "I0" else np.transpose(pre[k], (2, 1, 0)))
+        assert np.array_equal(got, want, equal_nan=True), k
+    x, R, u, I0 = pre["x_new"].T, pre["R_v"].T, np.transpose(pre["ip_filled"], (2, 1, 0)), pre["I0"].reshape(-1)
+    # 2. round 1 (zero input) and the first regression
+    S1 = _batch3(driver, pipeline.workload3(x, R, np.zeros_like(u), N, I0, np.zeros((n, S)), np.zeros(S)), tmp)
+    assert np.array_equal(S1[:, 2], ref["alpha_round1"])
+    D = 60
+    X = np.ascontiguousarray(synth.IP_MAXES[None, :n, None] - u[T - D:])
+    a1, b1, _, _ = _call(driver, "pipeline", ["nnls", np.transpose(X, (2, 1, 0)), S1[T - D:, 2].T, 100.0], nlhs=4, tmp=tmp)
+    assert np.array_equal(a1.T, ref["fit1"]["a"]) and np.array_equal(b1.reshape(-1), ref["fit1"]["b"])
+    # 3. round 2 and the second regression
+    S2 = _batch3(driver, pipeline.workload3(x, R, u, N, I0, a1.T, b1.reshape(-1)), tmp)
+    a2, b2, me2, it2 = _call(driver, "pipeline", ["nnls", np.transpose(X, (2, 1, 0)), S2[T - D:, 2].T, 100.0], nlhs=4, tmp=tmp)
+    assert np.array_equal(a2.T, ref["fit2"]["a"]) and np.array_equal(b2.reshape(-1), ref["fit2"]["b"])
+    assert np.array_equal(me2.reshape(-1), ref["fit2"]["min_err"]) and np.array_equal(it2.reshape(-1), ref["fit2"]["iters"])
+    a2, b2 = a2.T, b2.reshape(-1)
+    # 4. forecast filter (last plan held over the horizon)
+    R_mean = R.sum(axis=0) / T
+    xh = np.concatenate([x, np.full((H_, S), np.nan)]); Rh = np.concatenate([R, np.repeat(R_mean[None], H_, 0)])
+    Sf = _batch3(driver, pipeline.workload3(xh, Rh, np.concatenate([u, np.repeat(u[-1:], H_, 0)]), N, I0, a2, b2), tmp)
+    hist = Sf[:T]
+    assert np.array_equal(hist, ref["historic"])
+    # 5. the sweep of all regions in one call: per-region inputs only
+    reg = pipeline.sweep_region_inputs(N, I0, a2, b2, n)
+    wts = np.ones((n, S))
+    sp = pipeline.scoring_region_inputs(hist[T - 1], a2, b2, synth.IP_MAXES[:n], wts)
+    J0p = np.cumsum(hist[:, 0] * hist[:, 1] * hist[:, 2], axis=0)[-1]
+    J1p = np.cumsum((wts[None] * u).reshape(T * n, S), axis=0)[-1]
+    eps = synth.epsilon_grid(P)
+    u_nan = np.concatenate([u, np.full((H_, n, S), np.nan)])
+    res = _call(driver, "pipeline", ["prescribe", xh.T, np.transpose(u_nan, (2, 1, 0)), Rh.T, reg["prm"].T, reg["s_init"].T, reg["Ps_init"].T,
+                                     reg["s_final"].T, reg["Ps_final"].T, reg["Q"].T, eps.reshape(-1, 1), sp.T, J0p.reshape(-1, 1),
+                                     J1p.reshape(-1, 1), float(T), 21.0, 1.0, 0.0, np.zeros((0, 0))], tmp=tmp)
+    J0, J1, on_front, I_opt, u_opt, S_opt = res
+    assert J0.shape == (P, S) and u_opt.shape == (S, n, T + H_) and S_opt.shape == (S, 6, T + H_)
+    assert np.array_equal(J0.T, ref["J0"]) and np.array_equal(J1.T, ref["J1"])
+    assert np.array_equal(on_front.T.astype(bool), ref["front"])
+    assert np.array_equal(I_opt.reshape(-1) - 1, ref["i_opt"])                     # the gateway returns MATLAB's 1-based index
+    assert np.array_equal(np.transpose(u_opt, (2, 1, 0))[T:], ref["prescription"])
+    # 6. random-NPI Monte-Carlo scenarios of every region
+    nz = 40
+    mcr = batch.random_npi_mc(sp, np.zeros((n, S)), nz, H_, seed=5, J0_prefix=J0p, J1_prefix=J1p, prefix_days=T, device=gpu_device)
+    m0, m1 = _call(driver, "pipeline", ["mc", sp.T, np.zeros((S, n)), float(nz), float(H_), 5.0, np.zeros((0, 0)), J0p.reshape(-1, 1),
+                                        J1p.reshape(-1, 1), float(T)], nlhs=2, tmp=tmp)
+    assert np.array_equal(m0.T, mcr["J0"].cpu().numpy()) and np.array_equal(m1.T, mcr["J1"].cpu().numpy())
+    _call(driver, "pipeline", ["nonsense"], expect_error="unknown command", tmp=tmp)
