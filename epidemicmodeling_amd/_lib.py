@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
     "epi_preprocess_workspace_bytes", "epi_preprocess_device", "epi_nnls_affine_fit_device",
     "epi_sweep_run_device", "epi_sweep_prescribe_host", "epi_preprocess_host", "epi_nnls_affine_fit_host", "epi_random_npi_mc_host",
+    "epi_sir_sim_device", "epi_sir_sim_host",
 ]
 
 
@@ -203,6 +204,10 @@ def lib():
         h.epi_sweep_prescribe_host.restype = C.c_int
         h.epi_sweep_prescribe_host.argtypes = [C.POINTER(PrescribeDesc), C.POINTER(PrescribeInputs), C.POINTER(PrescribeOutputs),
                                                C.c_int, C.POINTER(C.c_int), C.c_char_p]
+        h.epi_sir_sim_device.restype = C.c_int
+        h.epi_sir_sim_device.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+        h.epi_sir_sim_host.restype = C.c_int
+        h.epi_sir_sim_host.argtypes = [C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p]
         h.epi_preprocess_host.restype = C.c_int
         h.epi_preprocess_host.argtypes = [C.POINTER(PreDesc)] + [C.c_void_p] * 4 + [C.POINTER(PreOutputs), C.c_int, C.c_char_p]
         h.epi_nnls_affine_fit_host.restype = C.c_int

@@ -2133,6 +2133,15 @@ int epi_si_controlled_device(int32_t B, int32_t K, int32_t Sa, double dt, const 
     return EPI_OK;
 }
 
+int epi_sir_sim_device(int32_t B, int32_t K, double dt, const double *prm, double *out, void *stream, char *err)
+{
+    if (B < 1 || K < 1 || !prm || !out) { set_err(err, "bad SIR arguments"); return EPI_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(sir_sim, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, K, dt, prm, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(err, e, "sir_sim launch");
+    return EPI_OK;
+}
+
 // ---- host-pointer variants of the simulators and the cost (what a MEX gateway binds: matlab/epiekf_sim_mex.cpp) ----
 namespace {
 struct HostStage {   // device copies of host arrays for one call; frees everything on destruction
@@ -2232,6 +2241,18 @@ int epi_npi_cost_host(int32_t B, int32_t T, int32_t n_npi, int32_t Su, int32_t w
     if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
     return h.finish(epi_npi_cost_device(B, T, n_npi, Su, weights_per_day, (const int32_t *)dus, (const double *)dn,
                                         (const double *)du, (const double *)dw, (double *)d0, (double *)d1, nullptr, err), err);
+}
+
+int epi_sir_sim_host(int32_t B, int32_t K, double dt, const double *prm, double *out, int device, char *err)
+{
+    if (B < 1 || K < 1) { set_err(err, "bad SIR arguments"); return EPI_ERR_BAD_ARG; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return hip_fail(err, e, "hipSetDevice");
+    HostStage h;
+    const void *dp = h.in(prm, (size_t)6 * B * 8);
+    void *dout = h.out(out, (size_t)K * 3 * B * 8);
+    if (h.e != hipSuccess) return hip_fail(err, h.e, "host staging");
+    return h.finish(epi_sir_sim_device(B, K, dt, (const double *)dp, (double *)dout, nullptr, err), err);
 }
 
 int epi_preprocess_host(const epi_pre_desc *d, const double *cases, const double *deaths, const double *population,

@@ -186,6 +186,25 @@ __global__ __launch_bounds__(256) void si_controlled(int B, int K, int Sa, doubl
     }
 }
 
+// testScripts/testSIR01.m:28-36 (BASELINE config 1), one lane per parameter set: the 3-compartment SIR with return flow
+// r -> s, forward Euler, no clamps; prm [6][B] = alpha, beta, gamma, s0, i0, r0; out [K][3][B], first sample = initial state
+__global__ __launch_bounds__(256) void sir_sim(int B, int K, double dt, const double *__restrict__ prm, double *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    const double alpha = prm[c], beta = prm[(size_t)B + c], gamma = prm[(size_t)2 * B + c];
+    double s = prm[(size_t)3 * B + c], i = prm[(size_t)4 * B + c], r = prm[(size_t)5 * B + c];
+    out[c] = s; out[(size_t)B + c] = i; out[(size_t)2 * B + c] = r;
+    for (int t = 0; t < K - 1; t++) {
+        const double sn = (-alpha * s * i + gamma * r) * dt + s;      // :33
+        const double in = (alpha * s * i - beta * i) * dt + i;        // :34
+        const double rn = (beta * i - gamma * r) * dt + r;            // :35
+        s = sn; i = in; r = rn;
+        double *o = out + (size_t)(t + 1) * 3 * B + c;
+        o[0] = s; o[(size_t)B] = i; o[(size_t)2 * B] = r;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // the cost-weight sweep from per-region inputs (epi_sweep_prescribe_host)
 // ---------------------------------------------------------------------------

@@ -116,3 +116,15 @@ def random_npi_mc(sp, u_min, n_scen, K, seed=0, z=None, J0_prefix=None, J1_prefi
                                            int(device), err)
     _lib.check(rc, err)
     return out
+
+
+def sir(alpha, beta, gamma, s0, i0, r0, K, dt, device=0):
+    """testScripts/testSIR01.m:15-36 (BASELINE config 1): the 3-compartment SIR with return flow, forward Euler.  Scalars or
+    arrays of B parameter sets; returns (s, i, r), each [K, B] (the first sample is the initial state)."""
+    prm = np.ascontiguousarray(np.stack(np.broadcast_arrays(*[np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in (alpha, beta, gamma, s0, i0, r0)])))
+    B = prm.shape[1]
+    out = np.empty((int(K), 3, B))
+    err = C.create_string_buffer(256)
+    rc = _lib.lib().epi_sir_sim_host(B, int(K), float(dt), prm.ctypes.data, out.ctypes.data, int(device), err)
+    _lib.check(rc, err)
+    return out[:, 0], out[:, 1], out[:, 2]

@@ -467,6 +467,12 @@ int epi_si_controlled_device(int32_t B, int32_t K, int32_t Sa, double dt, const 
 int epi_si_controlled_host(int32_t B, int32_t K, int32_t Sa, double dt, const int32_t *alpha_series, const double *alpha,
                            const double *prm, double *s, double *i, int device, char *err);
 
+/* testScripts/testSIR01.m:15-36 (BASELINE config 1) batched: the 3-compartment SIR with return flow r -> s, forward Euler
+ * without clamps, s(t+1) = (-alpha s i + gamma r) dt + s etc.  prm [6][B] = alpha, beta, gamma, s0, i0, r0 per parameter set;
+ * out [K][3][B] (rows s, i, r; the first sample is the initial state, :28-30). */
+int epi_sir_sim_device(int32_t B, int32_t K, double dt, const double *prm, double *out, void *stream, char *err);
+int epi_sir_sim_host(int32_t B, int32_t K, double dt, const double *prm, double *out, int device, char *err);
+
 /* Host-pointer variants of the three entry points above (same arrays in host memory; the library stages them through
  * device `device` and synchronises): what a MEX gateway for SIalpha_Controlled.m / SEIRP.m / SEIRPSaturatedResource.m /
  * NPICost.m binds (matlab/epiekf_sim_mex.cpp). */

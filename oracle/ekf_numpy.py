@@ -458,6 +458,17 @@ def si_controlled(alpha, beta, s0, i0, K, dt):
     return s, i
 
 
+def sir(alpha, beta, gamma, s0, i0, r0, K, dt):
+    """testScripts/testSIR01.m:28-36 (3-compartment SIR with return flow r -> s, forward Euler, no clamps)."""
+    s = np.zeros(K); i = np.zeros(K); r = np.zeros(K)
+    s[0], i[0], r[0] = s0, i0, r0
+    for t in range(K - 1):
+        s[t + 1] = (-alpha * s[t] * i[t] + gamma * r[t]) * dt + s[t]
+        i[t + 1] = (alpha * s[t] * i[t] - beta * i[t]) * dt + i[t]
+        r[t + 1] = (beta * i[t] - gamma * r[t]) * dt + r[t]
+    return s, i, r
+
+
 def seirp(alpha_e, alpha_i, kappa, rho, beta, mu, gamma, s0, e0, i0, r0, p0, T, dt):
     K = int(round(T / dt))
     s = np.zeros(K); e = np.zeros(K); i = np.zeros(K); r = np.zeros(K); p = np.zeros(K)

@@ -966,6 +966,19 @@ void orc_si_controlled(const double *alpha, double beta, double s0, double i0, i
     }
 }
 
+/* testScripts/testSIR01.m:15-36 -- the 3-compartment SIR with return flow r -> s (BASELINE config 1), forward Euler,
+ * no clamps; each line evaluated as written: (rhs) * dt + state. */
+void orc_sir(double alpha, double beta, double gamma, double s0, double i0, double r0, int K, double dt, double *s, double *i,
+             double *r)
+{
+    s[0] = s0; i[0] = i0; r[0] = r0; /* :28-30 */
+    for (int t = 0; t < K - 1; t++) {
+        s[t + 1] = (-alpha * s[t] * i[t] + gamma * r[t]) * dt + s[t]; /* :33 */
+        i[t + 1] = (alpha * s[t] * i[t] - beta * i[t]) * dt + i[t];   /* :34 */
+        r[t + 1] = (beta * i[t] - gamma * r[t]) * dt + r[t];          /* :35 */
+    }
+}
+
 void orc_seirp(const double *alpha_e, const double *alpha_i, const double *kappa, const double *rho,
                const double *beta, const double *mu, const double *gamma, double s0, double e0,
                double i0, double r0, double p0, int K, double dt, double *s, double *e, double *i,

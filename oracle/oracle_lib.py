@@ -346,3 +346,11 @@ def nnls(Cm, d):
     x = np.zeros(n)
     lib().orc_nnls_gram(C.c_int(n), _dp(G), _dp(h), C.c_double(tol), _dp(x))
     return x
+
+
+def sir(alpha, beta, gamma, s0, i0, r0, K, dt):
+    """testScripts/testSIR01.m:28-36 through the C restatement (orc_sir)."""
+    s, i, r = np.zeros(K), np.zeros(K), np.zeros(K)
+    lib().orc_sir(C.c_double(alpha), C.c_double(beta), C.c_double(gamma), C.c_double(s0), C.c_double(i0), C.c_double(r0),
+                  C.c_int(K), C.c_double(dt), _dp(s), _dp(i), _dp(r))
+    return s, i, r

@@ -587,3 +587,22 @@ def test_random_problems_c_oracle_vs_numpy_restatement():
                 assert np.array_equal(nd["pinv_rank"], ob["pinv_rank"][:, c]), (kind, T, c)
 
     run()
+
+
+def test_sir_config1_two_readings_agree_and_conserve_mass():
+    """BASELINE config 1, testScripts/testSIR01.m:15-36: alpha 0.5, beta 0.05, gamma 0.04, N = 84e6, dt = 0.1, K = 1500.
+    The C and the NumPy reading of the three Euler lines agree bit for bit (same operation order, nothing to reduce), the
+    right-hand sides sum to zero so s + i + r stays 1 up to rounding, and the epidemic does what the script plots: a single
+    wave, then the return flow r -> s settles into the endemic state i* > 0."""
+    from oracle import ekf_numpy as en
+    from oracle import oracle_lib as olib
+    N, K, dt = 84.0e6, 1500, 0.1
+    a = olib.sir(0.5, 0.05, 0.04, (N - 1) / N, 1 / N, 0.0, K, dt)
+    b = en.sir(0.5, 0.05, 0.04, (N - 1) / N, 1 / N, 0.0, K, dt)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    s, i, r = a
+    assert np.abs(s + i + r - 1.0).max() < 1e-12
+    assert s[0] == (N - 1) / N and i[0] == 1 / N and r[0] == 0.0
+    assert 0.3 < i.max() < 1.0 and np.argmax(i) * dt < 100.0          # one wave inside the simulated 150 days
+    assert i[-1] > 0.05 and s[-1] > 0.05                              # gamma > 0: not the SIR burn-out, an endemic level
