@@ -294,8 +294,12 @@ static int sym_pinv_two_sided(int m, const double *A, double *X)
  * symmetric matrix.  On the headline sweep's covariances the two routes agree on the rank everywhere and on X to 2e-12,
  * and both stand at the same distance from a LAPACK SVD evaluation (tests/test_oracle.py). */
 #define ORC_PINV_MAX_SWEEPS 30
-int orc_sym_pinv(int m, const double *A, double *X)
+/* route (may be NULL): 0 = the factorisation route, 1 = handed to the two-sided Jacobi; sweeps (may be NULL): one-sided
+ * sweeps run (the last one finds nothing to rotate) */
+int orc_sym_pinv_ex(int m, const double *A, double *X, int *route, int *sweeps)
 {
+    if (route) *route = 0;
+    if (sweeps) *sweeps = 0;
     double a[MM * MM], G[MM * MM];
     double amax = 0.0;
     for (int i = 0; i < m * m; i++) amax = fmax(amax, fabs(A[i]));
@@ -345,9 +349,13 @@ int orc_sym_pinv(int m, const double *A, double *X)
         for (int i = 0; i < m; i++) indefinite |= (!used[i] && a[IX(i, i, m)] < -0.25 * noise);
         r = k + 1;
     }
-    if (indefinite) return sym_pinv_two_sided(m, A, X);
+    if (indefinite) {
+        if (route) *route = 1;
+        return sym_pinv_two_sided(m, A, X);
+    }
     for (int sweep = 1; sweep <= ORC_PINV_MAX_SWEEPS; sweep++) {
         int rotated = 0;
+        if (sweeps) *sweeps = sweep;
         for (int p = 0; p < r - 1; p++)
             for (int q = p + 1; q < r; q++) {
                 double al = 0.0, be = 0.0, ga = 0.0;
@@ -399,6 +407,8 @@ int orc_sym_pinv(int m, const double *A, double *X)
         }
     return rank;
 }
+
+int orc_sym_pinv(int m, const double *A, double *X) { return orc_sym_pinv_ex(m, A, X, NULL, NULL); }
 
 /* ---------- MATLAB mrdivide, square right operand: X = B/A = (A'\B')' ----------
  * dgetf2 (unblocked right-looking LU, first-max partial pivoting, reciprocal

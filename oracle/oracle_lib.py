@@ -354,3 +354,15 @@ def sir(alpha, beta, gamma, s0, i0, r0, K, dt):
     lib().orc_sir(C.c_double(alpha), C.c_double(beta), C.c_double(gamma), C.c_double(s0), C.c_double(i0), C.c_double(r0),
                   C.c_int(K), C.c_double(dt), _dp(s), _dp(i), _dp(r))
     return s, i, r
+
+
+def sym_pinv_ex(A):
+    """(X, rank, route, sweeps) of orc_sym_pinv_ex: route 0 = pivoted Cholesky + one-sided Jacobi, 1 = two-sided Jacobi (the
+    matrix is not positive semi-definite up to rounding)."""
+    A = np.asfortranarray(np.asarray(A, dtype=np.float64))
+    m = A.shape[0]
+    X = np.zeros((m, m), order="F")
+    route, sweeps = C.c_int(0), C.c_int(0)
+    lib().orc_sym_pinv_ex.restype = C.c_int
+    r = lib().orc_sym_pinv_ex(C.c_int(m), _dp(A), _dp(X), C.byref(route), C.byref(sweeps))
+    return np.array(X), int(r), route.value, sweeps.value

@@ -20,11 +20,13 @@ def build(draw):
     R = draw(st.integers(1, 4)); E = draw(st.integers(1, 5))
     T_hist = draw(st.integers(1, 36)); hor = draw(st.integers(0, 12))
     # one problem in six is long enough (T >= 128) for the launch that pipelines the forward pass in time with the pinv grid
-    # (time_pipe = 1 forces it, 0 picks it for batches this small, -1 keeps it off); not the time-flipped six-state wrapper, whose
-    # costates overflow over that many days (non-finite values may then be placed differently)
+    # (time_pipe = 1 forces it, 0 picks it for batches this small, -1 keeps it off); not the time-flipped wrappers: they run
+    # the epidemic map backwards, and over that many days their covariances overflow (with every observation missing the
+    # three-state one reaches 1e152 and then Inf after ~140 days) -- DESIGN.md 2: a chain that has overflowed may carry its
+    # non-finite values in other places than the dense oracle (a 4 000-example hunt of round 3 found exactly that case)
     if draw(st.sampled_from([False] * 5 + [True])):
         T_hist = draw(st.integers(128, 170)); hor = draw(st.integers(0, 30))
-        kind = "sia6" if kind == "sia6_bwd" else kind
+        kind = {"sia6_bwd": "sia6", "sia3_bwd": "sia3"}.get(kind, kind)
     seed = draw(st.integers(0, 10 ** 6))
     rng = np.random.default_rng(seed)
     if kind == "sia3":

@@ -236,6 +236,61 @@ def test_pinv_zero_and_rank_one():
     assert np.allclose(X, np.outer(v, v) / (v @ v) ** 2, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("m", [3, 6])
+def test_pinv_kat_graded_semi_definite_covariances(m):
+    """What GenericExtendedKalmanFilter.m:215 hands to pinv: positive semi-definite, strongly graded (D B D with a
+    well-conditioned B and scales spread over up to 60 decades), numerically rank deficient.  These take the factorisation
+    route (pivoted Cholesky + one-sided Jacobi), agree with the LAPACK evaluation on the rank wherever the spectrum is
+    unambiguous, and on X to what a kept eigenvalue's conditioning allows; the sweep count stays far from the cap."""
+    from oracle import ekf_numpy as enp
+    from oracle import oracle_lib as olib
+    rng = np.random.default_rng(100 + m)
+    worst_sweeps = 0
+    for trial in range(60):
+        r_true = int(rng.integers(1, m + 1))
+        F = rng.standard_normal((m, r_true))
+        D = 10.0 ** rng.uniform(-30 if trial % 2 else -3, 0, size=m)
+        A = (D[:, None] * (F @ F.T)) * D[None, :]
+        A = (A + A.T) / 2
+        X, rk, route, sweeps = olib.sym_pinv_ex(A)
+        worst_sweeps = max(worst_sweeps, sweeps)
+        Xn, rn = enp.matlab_pinv(A)
+        sv = np.linalg.svd(A, compute_uv=False)
+        tol = m * enp.matlab_eps(sv[0])
+        if np.all((sv > tol * 50) | (sv < tol / 50)):
+            # (an eigenvalue AT the cut-off may send the matrix to the two-sided route: what is left of the factorisation
+            # is then neither negligible nor clearly positive; both routes are valid there)
+            assert route == 0, (trial, "a positive semi-definite matrix with a clear spectrum must not need the two-sided route")
+            assert rk == rn, (trial, rk, rn, sv / tol)
+            bound = 50 * np.finfo(float).eps * sv[0] / sv[rn - 1]
+            assert np.max(np.abs(X - Xn)) <= max(1e-9, bound) * np.max(np.abs(Xn)), trial
+        assert np.array_equal(X, X.T)
+    assert worst_sweeps <= 8
+
+
+def test_pinv_routes():
+    """Indefinite and negative semi-definite arguments are not covariances, but pinv is defined for them (singular values =
+    |eigenvalues|): they take the two-sided Jacobi route and agree with the LAPACK evaluation; a semi-definite matrix with
+    exact zero rows / columns stays on the factorisation route."""
+    from oracle import ekf_numpy as enp
+    from oracle import oracle_lib as olib
+    rng = np.random.default_rng(5)
+    Qm, _ = np.linalg.qr(rng.standard_normal((6, 6)))
+    for lam in ([3.0, 1.0, 0.5, -0.2, -1.0, -4.0], [-1.0, -2.0, -3.0, -4.0, -5.0, -6.0], [1.0, 0.0, 0.0, -1.0, 0.0, 0.0]):
+        A = (Qm * np.array(lam)) @ Qm.T
+        A = (A + A.T) / 2
+        X, rk, route, _ = olib.sym_pinv_ex(A)
+        Xn, rn = enp.matlab_pinv(A)
+        assert route == 1 and rk == rn and np.max(np.abs(X - Xn)) <= 1e-12 * np.max(np.abs(Xn))
+    A = np.zeros((6, 6)); A[0, 1] = A[1, 0] = 1.0                 # zero diagonal, non-zero off-diagonal: indefinite
+    X, rk, route, _ = olib.sym_pinv_ex(A)
+    assert route == 1 and rk == 2 and np.allclose(X, A)
+    B = np.zeros((6, 6)); B[1, 1] = 4.0; B[4, 4] = 1e-30; B[1, 4] = B[4, 1] = 1e-15       # rank 1 in double precision
+    X, rk, route, _ = olib.sym_pinv_ex(B)
+    Xn, rn = enp.matlab_pinv(B)
+    assert route == 0 and rk == rn == 1 and np.max(np.abs(X - Xn)) <= 1e-12 * np.max(np.abs(Xn))
+
+
 def test_mrdivide_matches_lapack():
     from oracle import ekf_numpy as enp
     from oracle import oracle_lib as olib

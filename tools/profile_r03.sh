@@ -1,6 +1,6 @@
-# Collects the round-2 profiles on the GPU box (run through gpurun); results land in gpurun_out/r02/.
+# Collects the round-3 profiles on the GPU box (run through gpurun); results land in gpurun_out/r03/.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 SQ="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats75k -o bench -- python3 $R/bench.py --no-cpu-baseline > $O/bench_cfg4_under_rocprof.json 2>/dev/null && echo stats75k
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats9375 -o bench -- python3 $R/bench.py --no-cpu-baseline --regions 75 --eps 125 > $O/bench_shard9375_under_rocprof.json 2>/dev/null && echo stats9375
