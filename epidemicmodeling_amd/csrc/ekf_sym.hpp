@@ -406,7 +406,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
 // ---------------------------------------------------------------------------
 template <int M>
 struct BwdIn {   // everything smoother step k reads: forward quantities of step k and X = pinv(P(k+1|k))
-    double Sp[M], Pp[M * (M + 1) / 2], u[kNpi], X[M * M];
+    double Sp[M], Pp[M * (M + 1) / 2], u[kNpi], X[M * (M + 1) / 2];    // P_PLUS and X packed (both symmetric bit for bit)
     int rk;
 };
 template <int M, int FLIP, int STOR = 0>
@@ -499,7 +499,12 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     };
     auto fetch_pp = [&](int k, BwdIn<M> &d) { load_sym<M>(a.P_PLUS, tpos<FLIP>(k, T), lay, d.Pp); };
     // (unused garbage where the :211 guard fired, rk < 0)
-    auto fetch_x = [&](int k, BwdIn<M> &d) { load_packed<M>(a.X, tpos<FLIP>(k + 1, T), lay, d.X); };
+    auto fetch_x = [&](int k, BwdIn<M> &d) {
+        unsigned voff, rowb;
+        const rsrc_t r = lay_slice(a.X, tpos<FLIP>(k + 1, T), NS, lay, voff, rowb);
+#pragma unroll
+        for (int e = 0; e < NS; e++) d.X[e] = bld(r, voff, (unsigned)e * rowb);
+    };
     int t_pend = -1, rank_pend = -1;
     double u_pend[kNpi];
 #pragma unroll
@@ -567,9 +572,9 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
                 }
 #pragma unroll
                 for (int j = 0; j < M; j++) {
-                    double acc = PAr[0] * cur.X[IXM(0, j)];
+                    double acc = PAr[0] * cur.X[sidx(0, j)];
 #pragma unroll
-                    for (int q = 1; q < M; q++) acc = fma(PAr[q], cur.X[IXM(q, j)], acc);
+                    for (int q = 1; q < M; q++) acc = fma(PAr[q], cur.X[sidx(q, j)], acc);
                     J[IXM(i, j)] = acc;
                 }
             }
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         }
         if (PF & 4) {
 #pragma unroll
-            for (int e = 0; e < M * M; e++) cur.X[e] = nxt.X[e];
+            for (int e = 0; e < NS; e++) cur.X[e] = nxt.X[e];
         }
     };
     if ((PF & 1) && k_from >= k_to) fetch_small(k_from, cur);
