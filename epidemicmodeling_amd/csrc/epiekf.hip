@@ -953,11 +953,17 @@ static WsLayout ws_layout(const epi_batch_desc *d)
 // launch logic
 // ---------------------------------------------------------------------------
 // Lanes per wave for the one-chain-per-lane kernels.  `waves_per_simd` waves of such a kernel fit a SIMD (1 for the
-// 6-state kernels, 2 for the 3-state ones).  If cn/64 waves exceed what is resident at once, the launch would run
+// 6-state kernels, 2 for the 3-state ones).  6 states: if cn/64 waves exceed what is resident at once, the launch would run
 // in rounds and the last round would leave most SIMDs idle while its few waves are limited by what ONE compute unit
 // can pull from memory; narrower waves, a multiple of 8 lanes (64-byte segments), make every round equally full.
+// 3 states: always full 64-lane waves.  Their arrays have 3 and 9 rows, so a wave writes 1.3 / 4 KB per array and step, and
+// chunks that small only reach the HBM's rate when every row is a whole number of cache lines (64 lanes = 512 B):
+// profiles/layout_probe/run_rows.py measures 4.7 / 5.2 TB/s for 3- / 9-row chunks of 56 lanes against 6.2 / 6.3 TB/s with 64
+// (with 12 rows and more the width stops mattering), and BASELINE config 5 runs 20.6 -> 17.5 ms with full waves although its
+// last round is a third full (profiles/r03/README.md).
 static int balanced_lanes(int cn, int waves_per_simd, int dev)
 {
+    if (waves_per_simd >= 2) return kWave;
     const long cap = (long)simd_count(dev) * waves_per_simd;
     const long w64 = (cn + kWave - 1) / kWave;
     if (w64 <= cap) return kWave;
