@@ -20,6 +20,9 @@ extern "C" __global__ __launch_bounds__(64) void probe(double *out, int B, int T
         } else if (mode == 1) {
             double *p = out + ((size_t)t * gridDim.x + blockIdx.x) * rows * blk + lane;
             for (int r = 0; r < rows; r++) p[(size_t)r * blk] = v + r;
+        } else if (mode == 4) {     // [t][B/blk][row][lb]: blk lanes per wave in rows PADDED to lb doubles (rows start on a cache line)
+            double *p = out + ((size_t)t * gridDim.x + blockIdx.x) * rows * lb + lane;
+            for (int r = 0; r < rows; r++) p[(size_t)r * lb] = v + r;
         } else if (mode == 3) {
             double2 *p = (double2 *)out + ((size_t)t * gridDim.x + blockIdx.x) * (rows / 2) * blk + lane;
             for (int r = 0; r < rows / 2; r++) p[(size_t)r * blk] = make_double2(v + r, v - r);

@@ -32,3 +32,18 @@ for B, blk in ((75000, 40), (307200, 56), (307200, 64)):
             ts.append(a.elapsed_time(b))
         gb = B * T * rows * 8 / 1e9
         print(f"B {B:6d} blk {blk:2d} rows {rows:3d} T {T:5d}: {gb:5.1f} GB in {np.median(ts[1:]):6.2f} ms = {gb / np.median(ts[1:]) * 1e3:5.0f} GB/s", flush=True)
+
+# round 3, second question: 40 lanes per wave (what the six-state kernels want) in rows PADDED to 48 / 64 doubles (mode 4)
+print("padded rows, 40 lanes per wave:")
+B, blk = 75000, 40
+for lb in (40, 48, 64):
+    for rows in (1, 6, 12, 36, 104):
+        T = int(4.0e9 // (rows * ((B + blk - 1) // blk) * lb))
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); rc = h.run_probe(C.c_void_p(out.data_ptr()), B, T, rows, blk, 4, 0, lb, C.c_void_p(st.cuda_stream)); b.record()
+            torch.cuda.synchronize(); assert rc == 0
+            ts.append(a.elapsed_time(b))
+        gb = B * T * rows * 8 / 1e9
+        print(f"pitch {lb:2d} rows {rows:3d} T {T:5d}: {gb:5.1f} GB useful in {np.median(ts[1:]):6.2f} ms = {gb / np.median(ts[1:]) * 1e3:5.0f} GB/s", flush=True)
