@@ -99,6 +99,59 @@ def test_random_problems_match_the_oracle(gpu_device, data):
     assert np.array_equal(got["pinv_rank"], ref["pinv_rank"]), (kind, w.T, w.B, shape)
 
 
+@settings(max_examples=_N or 80, deadline=None, suppress_health_check=list(HealthCheck), derandomize=not _N)
+@given(st.data())
+def test_random_sweeps_through_the_one_call_entry(gpu_device, data):
+    """epi_sweep_run_device on randomly drawn sweeps -- observed days from 1, horizons from 1 day (no cut of the smoother) to
+    30, long histories (the time-pipelined launch), both lane mappings, layouts, output subsets, missing observations, a
+    dense-kernel batch now and then, with and without the Pareto filter: filter outputs equal the oracle's, (J0, J1), front
+    and I_opt equal the separate scoring / filter calls on the same u_opt_smooth, bit for bit."""
+    import torch
+    from epidemicmodeling_amd import batch
+    draw = data.draw
+    R = draw(st.integers(1, 5)); E = draw(st.integers(1, 9))
+    T_hist = draw(st.integers(128, 150)) if draw(st.sampled_from([False] * 4 + [True])) else draw(st.integers(1, 40))
+    hor = draw(st.integers(1, 30))
+    w = synth.make_cfg4(R, E, T_hist, hor)
+    rng = np.random.default_rng(draw(st.integers(0, 10 ** 6)))
+    if draw(st.booleans()):
+        w.x = w.x.copy(); w.x[:T_hist][rng.random((T_hist, w.x.shape[1])) < 0.2] = np.nan
+    if draw(st.sampled_from([False, False, False, True])):
+        w.Q = w.Q.copy(); w.Q[1] = 1e-13                       # non-diagonal Q_w: dense kernels, tail after the smoother
+    outputs = draw(st.sampled_from([None, ["u_opt_smooth"], ["u_opt_smooth", "S_SMOOTH"], ["u_opt_smooth", "P_SMOOTH", "rho", "S_PLUS"]]))
+    lane_block = draw(st.sampled_from([0, 0, 8, 16, 40, "auto"]))
+    shape = draw(st.sampled_from(["lane", "quad", "auto"]))
+    time_pipe = draw(st.sampled_from([0, 1, -1]))
+    with_front = draw(st.booleans())
+    n, B = w.n_npi, w.B
+    sp = np.zeros((batch.SIM_PRM_COUNT, B))
+    sp[0] = 1.0 - 1e-3 * rng.random(B); sp[1] = 1e-3 * rng.random(B); sp[2] = synth.ALPHA0 * (0.5 + rng.random(B))
+    sp[3] = w.prm[L_.PRM_ALPHA_MIN]; sp[4] = w.prm[L_.PRM_ALPHA_MAX]; sp[5] = w.prm[L_.PRM_GAMMA]
+    sp[6] = w.prm[L_.PRM_B]; sp[7] = w.prm[L_.PRM_BETA]; sp[11] = 1.0
+    sp[batch.SIM_A:batch.SIM_A + n] = w.prm[L_.PRM_A:L_.PRM_A + n]
+    sp[batch.SIM_U_MAX:batch.SIM_U_MAX + n] = w.prm[L_.PRM_U_MAX:L_.PRM_U_MAX + n]
+    sp[batch.SIM_W:batch.SIM_W + n] = rng.random((n, B)) + 0.5
+    to = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).to(gpu_device)
+    sp_d, j0_d, j1_d = to(sp), to(rng.random(B) * 1e-2), to(rng.random(B) * 40.0)
+    ref = H.oracle_batch(w)
+    dw = batch.DeviceWorkload(w, gpu_device)
+    r = batch.EkfRunner(dw, outputs=outputs, extras=True, lane_block=lane_block, shape=shape, time_pipe=time_pipe)
+    for t in list(r.out.values()) + [r.ws]:
+        t.fill_(float("nan"))
+    sc = r.run_sweep(T_hist, sp_d, j0_d, j1_d, n_regions=R if with_front else None)
+    torch.cuda.synchronize()
+    tag = (R, E, T_hist, hor, outputs, lane_block, shape, time_pipe, with_front)
+    for nme in r.out:
+        assert np.array_equal(r.unblocked(nme).cpu().numpy(), ref[nme], equal_nan=True), (tag, nme)
+    assert np.array_equal(r.unblocked("pinv_rank").cpu().numpy(), ref["pinv_rank"]), tag
+    J0, J1 = sc["J0"].clone(), sc["J1"].clone()
+    sc2 = batch.score_sweep(r.out["u_opt_smooth"], T_hist, sp_d, j0_d, j1_d, B=B)
+    assert torch.equal(J0, sc2["J0"]) and torch.equal(J1, sc2["J1"]), tag
+    if with_front:
+        on2, io2 = batch.pareto_front(sc2["J0"], sc2["J1"], R)
+        assert torch.equal(sc["on_front"].bool(), on2) and torch.equal(sc["i_opt"], io2), tag
+
+
 @settings(max_examples=_N or 60, deadline=None, suppress_health_check=list(HealthCheck), derandomize=not _N)
 @given(st.data())
 def test_random_preprocessing_matches_the_oracle(gpu_device, data):
