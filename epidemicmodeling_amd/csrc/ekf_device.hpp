@@ -606,8 +606,12 @@ constexpr int kPinvMaxSweeps = 30;
 // Au: upper triangle of A, packed (entry (i, j), i <= j, at i + j (j + 1) / 2); Xu: upper triangle of X, packed the same way.
 // Returns the rank kept; *indef: this lane's matrix is not positive semi-definite up to rounding and Xu / the rank are NOT
 // valid -- the caller runs sym_pinv_two_sided for it.
-template <int M>
-EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (M + 1) / 2], bool *capped, bool *indef_out)
+// lds: this lane's column of an LDS block of NS doubles per lane with a stride of LSTR doubles (scratch of the full-rank
+// route: the inverse of the triangular factor waits there while the other lanes of the wavefront iterate, and the result is
+// brought back from pivot order through it -- a per-lane permutation is one ds_write with a computed address).
+template <int M, int LSTR>
+EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (M + 1) / 2], bool *capped, bool *indef_out,
+                         double *lds)
 {
     constexpr int NS = M * (M + 1) / 2;
     auto sx = [](int i, int j) constexpr { return i <= j ? i + j * (j + 1) / 2 : j + i * (i + 1) / 2; };
@@ -631,11 +635,18 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
     bool indef = false;
 #pragma unroll
     for (int i = 0; i < M; i++) indef = indef || (a[sx(i, i)] < -0.25 * noise);
+    double tr0 = 0.0;                   // trace of the scaled matrix: an upper bound of its largest eigenvalue
+#pragma unroll
+    for (int i = 0; i < M; i++) tr0 = tr0 + a[sx(i, i)];
     double G[M * M];
 #pragma unroll
     for (int i = 0; i < M * M; i++) G[i] = 0.0;
     unsigned used = 0u;
     int r = 0;
+    int ord[M];                         // the pivot of factorisation step k
+    double ilv[M];                      // 1 / G(ord[k], k)
+#pragma unroll
+    for (int k = 0; k < M; k++) { ord[k] = 0; ilv[k] = 0.0; }
     bool active = !indef;
 #pragma unroll
     for (int k = 0; k < M; k++) {
@@ -706,6 +717,8 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
             G[IXM(i, k)] = go ? col[i] : 0.0;
         }
         used = go ? (used | (1u << (p & 31))) : used;
+        ord[k] = go ? p : ord[k];
+        ilv[k] = go ? il : ilv[k];
         // Schur complement of the free part.  (Entries of used rows are never read again, and neither is anything of a
         // lane that has stopped: both may take any value, so the update is not predicated.)
 #pragma unroll
@@ -719,6 +732,50 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
         active = go && !negd;
         r = go ? k + 1 : r;
     }
+    // Full rank, certified: every index has been a pivot and 1 / trace(inv(A)) -- a lower bound of the smallest eigenvalue;
+    // trace(inv(A)) is the squared Frobenius norm of the inverse of the triangular factor -- lies four cut-offs above the
+    // cut-off.  Then pinv(A) = inv(A) = P' (inv(Lp)' inv(Lp)) P with Lp the rows of G in pivot order (see the oracle):
+    // no iteration.  inv(Lp) is formed here, while G is at hand, and parked in LDS; the product follows at the end.
+    constexpr auto lt = [](int i, int j) constexpr { return i * (i + 1) / 2 + j; };      // lower triangle, packed by rows
+    bool cert = false;
+    {
+        const bool full = !indef && r == M;
+        if (__builtin_amdgcn_ballot_w64(full) != 0ull) {
+            double Lp[NS], Li[NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++) Lp[i] = 0.0;
+#pragma unroll
+            for (int k = 0; k < M; k++)
+#pragma unroll
+                for (int q = 0; q < M; q++) {               // a wavefront's matrices nearly always share the pivot order:
+                    const bool hit = full && ord[k] == q;   // one of the six candidates is in play, the others are skipped
+                    if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
+#pragma unroll
+                    for (int c = 0; c <= k; c++) Lp[lt(k, c)] = hit ? G[IXM(q, c)] : Lp[lt(k, c)];
+                }
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                Li[lt(j, j)] = ilv[j];
+#pragma unroll
+                for (int i = j + 1; i < M; i++) {
+                    double acc = Lp[lt(i, j)] * Li[lt(j, j)];
+#pragma unroll
+                    for (int k = j + 1; k < i; k++) acc = fma(Lp[lt(i, k)], Li[lt(k, j)], acc);
+                    Li[lt(i, j)] = -(acc * ilv[i]);
+                }
+            }
+            double fro = 0.0;
+#pragma unroll
+            for (int j = 0; j < M; j++)
+#pragma unroll
+                for (int i = j; i < M; i++) fro = fma(Li[lt(i, j)], Li[lt(i, j)], fro);
+            cert = full && (4.0 * ((double)M * eps_of(tr0)) * fro < 1.0);
+            if (__builtin_amdgcn_ballot_w64(cert) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < NS; i++) lds[i * LSTR] = Li[i];
+            }
+        }
+    }
     // one-sided Jacobi on the r columns of G.  The squared column norms are kept beside G and formed anew (same fma chain
     // the oracle runs at every test) for the two columns a rotation has touched.
     double nrm[M];
@@ -729,7 +786,7 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
         for (int i = 0; i < M; i++) s2 = fma(G[IXM(i, k)], G[IXM(i, k)], s2);
         nrm[k] = s2;
     }
-    bool done = indef || r < 2;
+    bool done = indef || cert || r < 2;
     bool cap = false;
     for (int sweep = 1; sweep <= kPinvMaxSweeps; sweep++) {
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
@@ -783,7 +840,7 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
     int rank = 0;
 #pragma unroll
     for (int k = 0; k < M; k++) {
-        const bool keep = k < r && lam[k] > tol;
+        const bool keep = !cert && k < r && lam[k] > tol;
         if (__builtin_amdgcn_ballot_w64(keep) == 0ull) continue;
         rank += keep ? 1 : 0;
         const double w = keep ? 1.0 / (lam[k] * lam[k]) : 0.0;
@@ -792,6 +849,33 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
         for (int c = 0; c < M; c++)
 #pragma unroll
             for (int rr = 0; rr <= c; rr++) Xu[sx(rr, c)] = fma(G[IXM(rr, k)] * w, G[IXM(c, k)], Xu[sx(rr, c)]);
+    }
+    if (__builtin_amdgcn_ballot_w64(cert) != 0ull) {
+        // the certified lanes: Xp = inv(Lp)' inv(Lp) in pivot order, then X(ord[i], ord[j]) = Xp(i, j) through LDS
+        double Li[NS], Xp[NS];
+#pragma unroll
+        for (int i = 0; i < NS; i++) Li[i] = lds[i * LSTR];
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i <= j; i++) {
+                double acc = Li[lt(j, i)] * Li[lt(j, j)];
+#pragma unroll
+                for (int k = j + 1; k < M; k++) acc = fma(Li[lt(k, i)], Li[lt(k, j)], acc);
+                Xp[sx(i, j)] = acc;
+            }
+        if (cert) {
+#pragma unroll
+            for (int j = 0; j < M; j++)
+#pragma unroll
+                for (int i = 0; i <= j; i++) {
+                    const int oa = ord[i] < ord[j] ? ord[i] : ord[j], ob = ord[i] < ord[j] ? ord[j] : ord[i];
+                    lds[(oa + ob * (ob + 1) / 2) * LSTR] = Xp[sx(i, j)];
+                }
+#pragma unroll
+            for (int i = 0; i < NS; i++) Xu[i] = lds[i * LSTR];
+            rank = M;
+        }
     }
 #pragma unroll
     for (int i = 0; i < NS; i++) Xu[i] = ldexp(Xu[i], -e);

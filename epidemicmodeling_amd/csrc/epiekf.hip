@@ -458,7 +458,11 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     // X is symmetric bit for bit: the workspace holds its packed upper triangle (M(M+1)/2 rows)
     double Xu[NSX];
     bool capped, indef;
-    int rank = sym_pinv_psd<M>(Pu, Xu, &capped, &indef);              // :215
+    // one LDS column per lane: scratch of the full-rank route, and later the b/z accumulators of the two-sided fall-back
+    constexpr int WG = pinv_wg<M>();
+    constexpr int LROWS = NSX > 2 * M ? NSX : 2 * M;
+    __shared__ double plds[LROWS * WG];
+    int rank = sym_pinv_psd<M, WG>(Pu, Xu, &capped, &indef, plds + threadIdx.x);              // :215
     unsigned voff_x, rowb_x;
     const rsrc_t rx = lay_slice(a.X, t1, NSX, lay, voff_x, rowb_x);
 #pragma unroll
@@ -468,8 +472,8 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
         // Not positive semi-definite up to rounding (never the case for a covariance the filter produced from a positive
         // semi-definite Ps_init): the two-sided Jacobi route on the matrix read again; the lanes concerned overwrite what
         // they stored above (nothing of the first route is live across this block).
-        constexpr int BZS = (M >= 6) ? pinv_wg<M>() : 0;
-        __shared__ double bzs[BZS ? 2 * M * BZS : 1];      // its b/z accumulators (one column per lane), see jacobi_eig
+        constexpr int BZS = (M >= 6) ? WG : 0;              // its b/z accumulators (one column per lane), see jacobi_eig
+        double *bzs = plds;
         double P[M * M], X[M * M];
 #pragma unroll
         for (int j = 0; j < M; j++)

@@ -289,13 +289,15 @@ static int sym_pinv_two_sided(int m, const double *A, double *X)
  *      squared column norms, its eigenvectors the normalised columns -- no eigenvector matrix is accumulated, and
  *      pre-conditioned by the pivoted factorisation the iteration needs 2 - 3.5 sweeps (Veselic & Hari 1989, Drmac 1997).
  *   3. X = sum over the kept columns of g g' / (g'g)^2.
+ * Where the factorisation runs through all m pivots and a cheap certificate shows every eigenvalue above the cut-off,
+ * steps 2-3 are skipped: X is the inverse, formed from the triangular factor (see the block after the loop).
  * A matrix that is not positive semi-definite up to rounding (a diagonal entry, or what is left when the factorisation
  * stops, that is not negligible against the cut-off) takes the two-sided Jacobi route above, which handles any
  * symmetric matrix.  On the headline sweep's covariances the two routes agree on the rank everywhere and on X to 2e-12,
  * and both stand at the same distance from a LAPACK SVD evaluation (tests/test_oracle.py). */
 #define ORC_PINV_MAX_SWEEPS 30
-/* route (may be NULL): 0 = the factorisation route, 1 = handed to the two-sided Jacobi; sweeps (may be NULL): one-sided
- * sweeps run (the last one finds nothing to rotate) */
+/* route (may be NULL): 0 = factorisation + one-sided Jacobi, 1 = handed to the two-sided Jacobi, 2 = full rank certified: the
+ * inverse from the factor; sweeps (may be NULL): one-sided sweeps run (the last one finds nothing to rotate) */
 int orc_sym_pinv_ex(int m, const double *A, double *X, int *route, int *sweeps)
 {
     if (route) *route = 0;
@@ -314,8 +316,11 @@ int orc_sym_pinv_ex(int m, const double *A, double *X, int *route, int *sweeps)
     const double stop = noise * 0x1p-20;
     int indefinite = 0;
     for (int i = 0; i < m; i++) indefinite |= (a[IX(i, i, m)] < -0.25 * noise);
-    int used[MM] = {0};
+    int used[MM] = {0}, order[MM] = {0};
+    double ilv[MM];
     int r = 0;
+    double tr0 = 0.0;                                    /* trace of the scaled matrix: >= its largest eigenvalue */
+    for (int i = 0; i < m; i++) tr0 = tr0 + a[IX(i, i, m)];
     for (int i = 0; i < m * m; i++) G[i] = 0.0;
     for (int k = 0; k < m && !indefinite; k++) {
         int p = -1;
@@ -343,6 +348,8 @@ int orc_sym_pinv_ex(int m, const double *A, double *X, int *route, int *sweeps)
         col[p] = l;
         for (int i = 0; i < m; i++) G[IX(i, k, m)] = col[i];
         used[p] = 1;
+        order[k] = p;
+        ilv[k] = il;
         for (int j = 0; j < m; j++)
             for (int i = 0; i <= j; i++)
                 if (!used[i] && !used[j]) a[IX(i, j, m)] = fma(-col[i], col[j], a[IX(i, j, m)]);
@@ -352,6 +359,43 @@ int orc_sym_pinv_ex(int m, const double *A, double *X, int *route, int *sweeps)
     if (indefinite) {
         if (route) *route = 1;
         return sym_pinv_two_sided(m, A, X);
+    }
+    if (r == m) {
+        /* Every index has been a pivot: A is positive definite as far as the factorisation can tell, and if ALL its
+         * eigenvalues lie above MATLAB's cut-off the pseudo-inverse is the inverse, which the factor gives directly:
+         * with Lp the rows of G in pivot order (a lower triangle), A = P' Lp Lp' P, so X = P' (inv(Lp)' inv(Lp)) P.
+         * The certificate needs no eigenvalue: lambda_min(A) >= 1 / trace(inv(A)) and trace(inv(A)) = the squared
+         * Frobenius norm of inv(Lp); the cut-off is at most m eps(trace(A)).  Held with a factor 4 in hand; a matrix
+         * that fails it (an eigenvalue within a few cut-offs of the cut-off) goes on to the Jacobi iteration below.
+         * (The filter's covariances of the first ~100 days of the headline sweep, and every 3 x 3 one: 4 300 -> 1 300
+         * instructions per matrix on the GPU.) */
+        double Lp[MM * MM], Li[MM * MM], Xp[MM * MM];
+        for (int k = 0; k < m; k++)
+            for (int c = 0; c <= k; c++) Lp[IX(k, c, m)] = G[IX(order[k], c, m)];
+        double fro = 0.0;
+        for (int j = 0; j < m; j++) {                      /* column j of inv(Lp), top to bottom */
+            Li[IX(j, j, m)] = ilv[j];
+            for (int i = j + 1; i < m; i++) {
+                double acc = Lp[IX(i, j, m)] * Li[IX(j, j, m)];
+                for (int k = j + 1; k < i; k++) acc = fma(Lp[IX(i, k, m)], Li[IX(k, j, m)], acc);
+                Li[IX(i, j, m)] = -(acc * ilv[i]);
+            }
+        }
+        for (int j = 0; j < m; j++)
+            for (int i = j; i < m; i++) fro = fma(Li[IX(i, j, m)], Li[IX(i, j, m)], fro);
+        if (4.0 * ((double)m * eps_of(tr0)) * fro < 1.0) {
+            for (int j = 0; j < m; j++)                     /* Xp = inv(Lp)' inv(Lp), upper triangle */
+                for (int i = 0; i <= j; i++) {
+                    double acc = Li[IX(j, i, m)] * Li[IX(j, j, m)];
+                    for (int k = j + 1; k < m; k++) acc = fma(Li[IX(k, i, m)], Li[IX(k, j, m)], acc);
+                    Xp[IX(i, j, m)] = acc;
+                    Xp[IX(j, i, m)] = acc;
+                }
+            for (int j = 0; j < m; j++)
+                for (int i = 0; i < m; i++) X[IX(order[i], order[j], m)] = ldexp(Xp[IX(i, j, m)], -e);
+            if (route) *route = 2;
+            return m;
+        }
     }
     for (int sweep = 1; sweep <= ORC_PINV_MAX_SWEEPS; sweep++) {
         int rotated = 0;

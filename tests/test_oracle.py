@@ -260,12 +260,54 @@ def test_pinv_kat_graded_semi_definite_covariances(m):
         if np.all((sv > tol * 50) | (sv < tol / 50)):
             # (an eigenvalue AT the cut-off may send the matrix to the two-sided route: what is left of the factorisation
             # is then neither negligible nor clearly positive; both routes are valid there)
-            assert route == 0, (trial, "a positive semi-definite matrix with a clear spectrum must not need the two-sided route")
+            assert route in (0, 2), (trial, "a positive semi-definite matrix with a clear spectrum must not need the two-sided route")
+            assert route == 0 or rk == m               # route 2 (the inverse from the factor) is for certified full rank only
             assert rk == rn, (trial, rk, rn, sv / tol)
             bound = 50 * np.finfo(float).eps * sv[0] / sv[rn - 1]
             assert np.max(np.abs(X - Xn)) <= max(1e-9, bound) * np.max(np.abs(Xn)), trial
         assert np.array_equal(X, X.T)
     assert worst_sweeps <= 8
+
+
+@pytest.mark.parametrize("m", [3, 6])
+def test_pinv_full_rank_route_is_the_inverse(m):
+    """Positive definite matrices whose smallest eigenvalue is certifiably above MATLAB's cut-off take route 2: X is the
+    inverse from the pivoted Cholesky factor -- equal to numpy's inverse and to the LAPACK pinv to what the conditioning allows,
+    symmetric bit for bit, for any pivot order (graded scales in random positions).  Matrices with an eigenvalue within a few
+    cut-offs of the cut-off must NOT take it (they go through the Jacobi iteration), and the two routes agree where both
+    apply."""
+    from oracle import ekf_numpy as enp
+    from oracle import oracle_lib as olib
+    rng = np.random.default_rng(300 + m)
+    took = 0
+    for trial in range(80):
+        Qm, _ = np.linalg.qr(rng.standard_normal((m, m)))
+        lam = 10.0 ** rng.uniform(-10 if trial % 3 else -2, 0, size=m)
+        D = 10.0 ** rng.uniform(-12, 0, size=m) if trial % 2 else np.ones(m)
+        A = (Qm * lam) @ Qm.T
+        A = (D[:, None] * A) * D[None, :]
+        A = (A + A.T) / 2
+        X, rk, route, _ = olib.sym_pinv_ex(A)
+        sv = np.linalg.svd(A, compute_uv=False)
+        tol = m * enp.matlab_eps(sv[0])
+        if route == 2:
+            took += 1
+            assert rk == m and sv[-1] > 2.0 * tol, (trial, sv[-1] / tol)
+            assert np.array_equal(X, X.T)
+            Xn, rn = enp.matlab_pinv(A)
+            assert rn == m
+            bound = 50 * np.finfo(float).eps * sv[0] / sv[-1]
+            assert np.max(np.abs(X - Xn)) <= max(1e-9, bound) * np.max(np.abs(Xn)), trial
+            assert np.max(np.abs(X @ A - np.eye(m))) <= max(1e-9, 100 * bound), trial
+        elif sv[-1] > tol * 1e6:
+            raise AssertionError((trial, "a comfortably positive definite matrix did not take the inverse route", sv[-1] / tol, route))
+    assert took >= 30
+    # an eigenvalue three cut-offs above the cut-off: full rank by MATLAB's rule, but not certifiable -> Jacobi route
+    Qm, _ = np.linalg.qr(rng.standard_normal((m, m)))
+    lam = np.ones(m); lam[-1] = 3.0 * m * np.finfo(float).eps
+    A = (Qm * lam) @ Qm.T; A = (A + A.T) / 2
+    X, rk, route, _ = olib.sym_pinv_ex(A)
+    assert route in (0, 1)
 
 
 def test_pinv_routes():
