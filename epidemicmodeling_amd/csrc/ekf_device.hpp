@@ -643,10 +643,8 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
     for (int i = 0; i < M * M; i++) G[i] = 0.0;
     unsigned used = 0u;
     int r = 0;
-    int ord[M];                         // the pivot of factorisation step k
-    double ilv[M];                      // 1 / G(ord[k], k)
-#pragma unroll
-    for (int k = 0; k < M; k++) { ord[k] = 0; ilv[k] = 0.0; }
+    unsigned ordw = 0u;                 // the pivot of factorisation step k in bits 3k .. 3k+2
+    auto ord = [&](int k) { return (int)((ordw >> (3 * k)) & 7u); };
     bool active = !indef;
 #pragma unroll
     for (int k = 0; k < M; k++) {
@@ -717,8 +715,8 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
             G[IXM(i, k)] = go ? col[i] : 0.0;
         }
         used = go ? (used | (1u << (p & 31))) : used;
-        ord[k] = go ? p : ord[k];
-        ilv[k] = go ? il : ilv[k];
+        ordw = go ? (ordw | ((unsigned)(p & 7) << (3 * k))) : ordw;
+        if (go) lds[k * LSTR] = il;         // 1 / G(ord[k], k): waits in LDS for the full-rank route (12 registers less)
         // Schur complement of the free part.  (Entries of used rows are never read again, and neither is anything of a
         // lane that has stopped: both may take any value, so the update is not predicated.)
 #pragma unroll
@@ -741,28 +739,31 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
     {
         const bool full = !indef && r == M;
         if (__builtin_amdgcn_ballot_w64(full) != 0ull) {
-            double Lp[NS], Li[NS];
+            // row by row: row i of Lp is gathered (a wavefront's matrices nearly always share the pivot order: one of the six
+            // candidate rows is in play, the others are skipped) and consumed into row i of the inverse at once
+            double Li[NS], ilv[M];
 #pragma unroll
-            for (int i = 0; i < NS; i++) Lp[i] = 0.0;
+            for (int k = 0; k < M; k++) ilv[k] = lds[k * LSTR];      // (garbage in the lanes that are not `full`: unused)
 #pragma unroll
-            for (int k = 0; k < M; k++)
+            for (int i = 0; i < M; i++) {
+                double Lr[M];
 #pragma unroll
-                for (int q = 0; q < M; q++) {               // a wavefront's matrices nearly always share the pivot order:
-                    const bool hit = full && ord[k] == q;   // one of the six candidates is in play, the others are skipped
+                for (int c = 0; c < M; c++) Lr[c] = 0.0;
+#pragma unroll
+                for (int q = 0; q < M; q++) {
+                    const bool hit = full && ord(i) == q;
                     if (__builtin_amdgcn_ballot_w64(hit) == 0ull) continue;
 #pragma unroll
-                    for (int c = 0; c <= k; c++) Lp[lt(k, c)] = hit ? G[IXM(q, c)] : Lp[lt(k, c)];
+                    for (int c = 0; c < i; c++) Lr[c] = hit ? G[IXM(q, c)] : Lr[c];
                 }
 #pragma unroll
-            for (int j = 0; j < M; j++) {
-                Li[lt(j, j)] = ilv[j];
+                for (int j = 0; j < i; j++) {
+                    double acc = Lr[j] * Li[lt(j, j)];
 #pragma unroll
-                for (int i = j + 1; i < M; i++) {
-                    double acc = Lp[lt(i, j)] * Li[lt(j, j)];
-#pragma unroll
-                    for (int k = j + 1; k < i; k++) acc = fma(Lp[lt(i, k)], Li[lt(k, j)], acc);
+                    for (int k = j + 1; k < i; k++) acc = fma(Lr[k], Li[lt(k, j)], acc);
                     Li[lt(i, j)] = -(acc * ilv[i]);
                 }
+                Li[lt(i, i)] = ilv[i];
             }
             double fro = 0.0;
 #pragma unroll
@@ -869,7 +870,8 @@ EPI_DEV int sym_pinv_psd(const double (&Au)[M * (M + 1) / 2], double (&Xu)[M * (
             for (int j = 0; j < M; j++)
 #pragma unroll
                 for (int i = 0; i <= j; i++) {
-                    const int oa = ord[i] < ord[j] ? ord[i] : ord[j], ob = ord[i] < ord[j] ? ord[j] : ord[i];
+                    const int oi = ord(i), oj = ord(j);
+                    const int oa = oi < oj ? oi : oj, ob = oi < oj ? oj : oi;
                     lds[(oa + ob * (ob + 1) / 2) * LSTR] = Xp[sx(i, j)];
                 }
 #pragma unroll
