@@ -383,7 +383,7 @@ def main():
                          "measured_copy": copy_bw,     # this box, this process: bytes read + written per second
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes,
                          "limiter": {"ekf_fwd": "HBM writes (store pattern) + lone-wave latency",
-                                     "eks_pinv": "fp64 VALU issue on the full-rank days, HBM on the others (pivoted Cholesky + one-sided Jacobi; SIMD VALU busy 74 % of the kernel's duration, profiles/r03/valu_summary.json)",
+                                     "eks_pinv": "HBM nearly everywhere (full-rank covariances are inverted from the pivoted Cholesky factor), fp64 VALU issue on the days where ranks 3-5 go through the one-sided Jacobi; SIMD VALU busy 67 % of the kernel's duration, profiles/r03/valu_summary.json",
                                      "eks_bwd": "lone-wave latency + HBM"}[dom]},
             "kernels": {**{k + "_ms": v for k, v in ms.items()},
                         **{k + "_GBs": alg[k] * steps_per_pass / (ms[k] * 1e-3) / 1e9 for k in ms},
