@@ -294,11 +294,11 @@ def main():
             if strong:
                 # a region's 250 cost weights may straddle two ranks: (J0, J1) of all shards are gathered to rank 0
                 # (the path's only collective; shards padded to the common block length) and filtered there
-                allj = batch.gather_shards_to_root(torch.stack([sc["J0"], sc["J1"]]), B_total)
+                allj = batch.gather_shards_to_root(sc["JJ"] if "JJ" in sc else torch.stack([sc["J0"], sc["J1"]]), B_total)
                 if rank == 0:
                     score_state["front"] = batch.pareto_front(allj[0].contiguous(), allj[1].contiguous(), regions_total)
             elif world > 1:
-                batch.gather_to_root(torch.stack([sc["J0"], sc["J1"]]))
+                batch.gather_to_root(sc["JJ"] if "JJ" in sc else torch.stack([sc["J0"], sc["J1"]]))
         elif world > 1:
             # no scoring: gather the per-chain smoothed state at the last observed day to rank 0
             batch.gather_to_root(runner.unblocked_at("S_SMOOTH", t_hist_idx).contiguous())

@@ -134,11 +134,13 @@ class EkfRunner:
         481-493) on the last T - t_hist days of the u_opt_smooth it wrote and, when `n_regions` is given (the batch then
         holds n_regions x P chains, region-major), the Pareto filter and optimum per region (:624-633) -- one library
         call, scoring and filter enqueued beside the smoother's pass over the observed days.  sp [48, B], J0_prefix /
-        J1_prefix [B] as for score_sweep.  Returns dict J0, J1 [B] (+ on_front bool-able int32 [R, P], i_opt int32 [R])."""
+        J1_prefix [B] as for score_sweep.  Returns dict J0, J1 [B] (views of JJ [2, B]) (+ on_front bool-able int32 [R, P],
+        i_opt int32 [R])."""
         dev = self.dw.device
         B = self.dw.B
         if self._sweep is None:
-            self._sweep = {"J0": torch.empty((B,), dtype=torch.float64, device=dev), "J1": torch.empty((B,), dtype=torch.float64, device=dev)}
+            jj = torch.empty((2, B), dtype=torch.float64, device=dev)     # (J0; J1) side by side: what the end-of-sweep gather sends
+            self._sweep = {"JJ": jj, "J0": jj[0], "J1": jj[1]}
         res = self._sweep
         sd = _lib.SweepDesc()
         sd.abi_version, sd.t_hist = _lib.ABI_VERSION, int(t_hist)
@@ -234,7 +236,8 @@ def gather_shards_to_root(t: torch.Tensor, B_total: int, group=None, dst: int = 
         dist.all_gather_into_tensor(buf, t, group=group)
         if dist.get_rank(group) != dst:
             return None
-        return torch.cat(list(buf.unbind(0)), dim=-1)[..., :B_total]
+        # [world, ..., per] -> [..., world * per]: the blocks side by side in chain order
+        return buf.movedim(0, -2).reshape(tuple(t.shape[:-1]) + (world * per,))[..., :B_total]
     parts = gather_to_root(t, group=group, dst=dst)
     if dist.get_rank(group) != dst:
         return None
