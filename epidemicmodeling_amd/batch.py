@@ -218,6 +218,13 @@ def gather_to_root(t: torch.Tensor, group=None, dst: int = 0):
     return bufs
 
 
+def blocks_side_by_side(buf: torch.Tensor) -> torch.Tensor:
+    """[world, ..., per] (what all_gather_into_tensor fills: one padded block per rank) -> [..., world * per], the blocks
+    next to each other in rank (= chain) order."""
+    world, per = buf.shape[0], buf.shape[-1]
+    return buf.movedim(0, -2).reshape(tuple(buf.shape[1:-1]) + (world * per,))
+
+
 def gather_shards_to_root(t: torch.Tensor, B_total: int, group=None, dst: int = 0):
     """Strong-scaling form of the end-of-sweep gather: `t` [..., n_r] holds this rank's block of a chain-minor result whose
     blocks come from shard_chains(B_total, rank, world) -- all of length ceil(B_total / world) except a shorter (possibly
@@ -236,8 +243,7 @@ def gather_shards_to_root(t: torch.Tensor, B_total: int, group=None, dst: int = 
         dist.all_gather_into_tensor(buf, t, group=group)
         if dist.get_rank(group) != dst:
             return None
-        # [world, ..., per] -> [..., world * per]: the blocks side by side in chain order
-        return buf.movedim(0, -2).reshape(tuple(t.shape[:-1]) + (world * per,))[..., :B_total]
+        return blocks_side_by_side(buf)[..., :B_total]
     parts = gather_to_root(t, group=group, dst=dst)
     if dist.get_rank(group) != dst:
         return None

@@ -142,3 +142,16 @@ def test_bench_started_bare_launches_its_own_ranks_and_returns_their_failure():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "must be launched with" not in r.stderr and ("ChildFailedError" in r.stderr or "rank" in r.stderr.lower()), r.stderr[-1500:]
+
+
+def test_gathered_blocks_are_reassembled_in_chain_order():
+    """What rank 0 does with the buffer ncclAllGather fills (batch.gather_shards_to_root, RCCL branch): [world, ..., per]
+    -> [..., world * per], identical to concatenating the ranks' blocks."""
+    import torch
+    from epidemicmodeling_amd import batch
+    g = torch.Generator().manual_seed(5)
+    for shape in [(4, 2, 7), (8, 5), (3, 2, 3, 4), (1, 2, 9)]:
+        buf = torch.rand(shape, generator=g, dtype=torch.float64)
+        want = torch.cat(list(buf.unbind(0)), dim=-1)
+        got = batch.blocks_side_by_side(buf)
+        assert got.shape == want.shape and torch.equal(got, want)
