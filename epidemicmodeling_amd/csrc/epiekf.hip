@@ -1139,7 +1139,12 @@ static hipError_t enqueue_tail(const KArgs &ka, const Tail &t, hipStream_t st)
 // Forward pass in time segments (percent of T where each ends).  pinv(P(k|k-1)) needs nothing but the forward pass's
 // output of day k and the smoother consumes X in REVERSE time order, so only the pinv grid of the last segment stands
 // between the end of the forward pass and the start of the smoother: the last segments are short.
-constexpr int kTimeCuts[] = {0, 40, 70, 90, 98, 100};
+// (re-measured in round 3 with the cheaper pinv: four segments ending at 50 / 85 / 97 / 100 % give 3.06-3.11 ms against
+// 3.12-3.16 for five ending at 40 / 70 / 90 / 98 / 100 % at 9 375 chains, level at 18 750: profiles/r03/time_cuts.txt)
+#ifndef EPI_TIME_CUTS
+#define EPI_TIME_CUTS 0, 50, 85, 97, 100
+#endif
+constexpr int kTimeCuts[] = {EPI_TIME_CUTS};
 constexpr int kTimeSeg = (int)(sizeof(kTimeCuts) / sizeof(kTimeCuts[0])) - 1;
 
 template <int M, int FLIP, int GENERIC>

@@ -129,8 +129,8 @@ typedef struct epi_batch_desc {
                              kernels (Ps_init bit-wise symmetric, Q_w diagonal): enqueue only those;
                              2 = dense kernels only */
     int32_t time_pipe;    /* a full call (phase 0) of a generic model on the packed kernels (path_hint = 1, R_v a per-day
-                             series, T >= 128) may run "pipelined in time": the forward kernel in five time segments (40, 30,
-                             20, 8, 2 % of the days), each followed by the eks_pinv grid of its days on a helper stream, so that
+                             series, T >= 128) may run "pipelined in time": the forward kernel in four time segments (50, 35,
+                             12, 3 % of the days), each followed by the eks_pinv grid of its days on a helper stream, so that
                              only the last days' pinv stands between the forward pass and the smoother.  0 = the library
                              decides (on when the batch leaves a quarter of the SIMDs idle -- the shards of the sweep on 2,
                              4, 8 GPUs), 1 = on, -1 = off.  Results are bit-identical either way. */
