@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--eps", type=int, default=250)
     ap.add_argument("--t-hist", type=int, default=400)
     ap.add_argument("--horizon", type=int, default=120)
-    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg3", "cfg5", "newcase"])
+    ap.add_argument("--workload", default="cfg4", choices=["cfg4", "cfg4-live", "cfg3", "cfg5", "newcase"],
+                    help="cfg4 = the series SURVEY.md 8(d) specifies (one wave, extinct long before day 400; the headline); "
+                         "cfg4-live = the same sweep on a living multi-wave epidemic (synth.make_cfg4(live=True))")
     ap.add_argument("--outputs", default="all", choices=["all", "reduced"],
                     help="reduced = u_opt_smooth + S_SMOOTH only (what TrainPredictPrescribeNPI.m:460-493 consumes)")
     ap.add_argument("--time-pipe", type=int, default=0, choices=[-1, 0, 1],
@@ -74,11 +76,12 @@ def parse():
 
 def make_workload(args, rank):
     from epidemicmodeling_amd import synth
-    if args.workload == "cfg4":
+    if args.workload in ("cfg4", "cfg4-live"):
+        live = args.workload == "cfg4-live"
         w = synth.make_cfg4(args.regions, args.eps, args.t_hist, args.horizon,
-                            region_offset=rank * args.regions if args.scaling == "weak" else 0)
-        name = (f"cfg4: SIAlphaModelEKFOptControlled sweep, {args.regions} regions x {args.eps} cost weights x "
-                f"({args.t_hist}+{args.horizon}) days")
+                            region_offset=rank * args.regions if args.scaling == "weak" else 0, live=live)
+        name = (f"{args.workload}: SIAlphaModelEKFOptControlled sweep, {args.regions} regions x {args.eps} cost weights x "
+                f"({args.t_hist}+{args.horizon}) days" + (", living multi-wave epidemic (reactive NPI history)" if live else ""))
     elif args.workload == "newcase":
         w = synth.make_newcase_sweep(args.regions, args.eps, args.t_hist, args.horizon)
         name = (f"newcase: NewCaseEKFEstimatorWithOptimalNPI sweep, {args.regions} regions x {args.eps} cost weights x "
@@ -92,23 +95,30 @@ def make_workload(args, rank):
     return w, name
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic_summary.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of profiles/traffic_probe.py on this same
-    workload, corrected by the calibration copy as MI355X_MICROARCH.md prescribes).  None if the bench is not
-    running the profiled workload."""
-    if args.workload != "cfg4" or (args.regions, args.eps, args.t_hist, args.horizon, args.outputs) != (300, 250, 400, 120, "all"):
+def pmc_summary(args):
+    """The committed rocprofv3 PMC summary of THIS workload and THESE kernel sources (profiles/r*/traffic_summary*.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of profiles/traffic_probe.py, corrected by the
+    calibration copy as MI355X_MICROARCH.md prescribes), or None."""
+    if args.workload not in ("cfg4", "cfg4-live") or (args.regions, args.eps, args.t_hist, args.horizon) != (300, 250, 400, 120):
         return None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_summary.json")))
+    tag = {"cfg4": "", "cfg4-live": "_live"}[args.workload] + ("" if args.outputs == "all" else "_reduced")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"traffic_summary{tag}.json")))
     if not files:
         return None
     summ = json.load(open(files[-1]))
     from epidemicmodeling_amd import _build
     if summ.get("kernel_src_sha16") != _build.source_hash():
         return None          # measured on other kernel sources than the ones this run executes: not quoted (stale)
-    ks = summ["kernels"]
-    for name, v in ks.items():
+    return summ
+
+
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from pmc_summary(); None if the bench is not running a profiled workload."""
+    summ = pmc_summary(args)
+    if summ is None:
+        return None
+    for name, v in summ["kernels"].items():
         if name.startswith(kernel):
             return v["hbm_bytes"]
     return None
@@ -244,7 +254,7 @@ def main():
 
     # scenario-scoring tail of the sweep (TrainPredictPrescribeNPI.m:481-493): per-chain (J0, J1) are what leaves
     # the GPU at the end of a pass; with N > 1 they are gathered to rank 0 (the path's only collective)
-    score = (not args.no_score) and args.workload == "cfg4" and "u_opt_smooth" in runner.out
+    score = (not args.no_score) and args.workload in ("cfg4", "cfg4-live") and "u_opt_smooth" in runner.out
     score_state = {}
 
     def prepare_scoring():
@@ -290,19 +300,34 @@ def main():
                                        score_state["J1p"], B=w.B)
                 if whole:
                     score_state["front"] = batch.pareto_front(sc["J0"], sc["J1"], w.Sx)
+        if world > 1:
+            # the path's only collective, bracketed so that a scaling curve can be decomposed: HIP events on the launch
+            # stream (over RCCL the collective is ordered against it) and the host's own clock (gloo rehearsal: the gather
+            # goes through host memory and blocks the host)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tg = time.perf_counter()
+            g0.record()
         if score and score_state:
             if strong:
                 # a region's 250 cost weights may straddle two ranks: (J0, J1) of all shards are gathered to rank 0
                 # (the path's only collective; shards padded to the common block length) and filtered there
                 allj = batch.gather_shards_to_root(sc["JJ"] if "JJ" in sc else torch.stack([sc["J0"], sc["J1"]]), B_total)
+                if world > 1:
+                    g1.record()
                 if rank == 0:
                     score_state["front"] = batch.pareto_front(allj[0].contiguous(), allj[1].contiguous(), regions_total)
             elif world > 1:
                 batch.gather_to_root(sc["JJ"] if "JJ" in sc else torch.stack([sc["J0"], sc["J1"]]))
+                g1.record()
         elif world > 1:
             # no scoring: gather the per-chain smoothed state at the last observed day to rank 0
             batch.gather_to_root(runner.unblocked_at("S_SMOOTH", t_hist_idx).contiguous())
+            g1.record()
+        if world > 1 and gather_log["on"]:
+            gather_log["events"].append((g0, g1))
+            gather_log["host_s"] += time.perf_counter() - tg
 
+    gather_log = {"on": False, "events": [], "host_s": 0.0}
     one_step()
     torch.cuda.synchronize(dev)
     if score:
@@ -319,17 +344,35 @@ def main():
     # bracketed by HIP events on the launch stream.  EPI_BENCH_STAGED=1: time the staged passes instead (round-1 behaviour).
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     staged = os.environ.get("EPI_BENCH_STAGED") == "1"
+    gather_log["on"] = True
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(evs[k] if staged else None)
     torch.cuda.synchronize(dev)
+    own_elapsed = time.perf_counter() - t0          # this rank's K passes, before it waits for the others
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gather_log["on"] = False
+    per_rank = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # per-rank figures for decomposing a scaling curve: every rank's own ms per pass and its gather time
+        g_ev = float(np.mean([a.elapsed_time(b) for a, b in gather_log["events"]])) if gather_log["events"] else 0.0
+        mine = torch.tensor([own_elapsed / args.steps * 1e3, g_ev, gather_log["host_s"] / args.steps * 1e3], dtype=torch.float64,
+                            device=dev if backend == "nccl" else "cpu")
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu().numpy()
+        per_rank = {"ms_per_step_by_rank": [float(v) for v in allr[:, 0]],
+                    "ms_per_step_min": float(allr[:, 0].min()), "ms_per_step_max": float(allr[:, 0].max()),
+                    "gather_ms_hip_events_by_rank": [float(v) for v in allr[:, 1]],
+                    "gather_ms_host_clock_by_rank": [float(v) for v in allr[:, 2]],
+                    "backend": backend, "rccl_ranks": int(dist.get_world_size()),
+                    "note": "ms_per_step_by_rank = each rank's own K passes (kernels + its part of the gather) before the closing "
+                            "barrier; gather_ms = the end-of-sweep gather of (J0, J1) alone, per pass"}
     if not staged:
         for k in range(args.steps):
             one_step(evs[k])
@@ -390,6 +433,17 @@ def main():
                         "whole_step_algorithmic_bytes": step_bytes, "whole_step_GBs": step_gbs,
                         "whole_step_frac_of_hbm_peak": step_gbs / HBM_PEAK_GBS},
         }
+        if per_rank is not None:
+            res["ranks"] = per_rank
+        # a figure that can be compared across boxes of different HBM speed: the pass time in units of what this box needs
+        # to move the pass's MEASURED traffic at its own copy bandwidth (1.0 = the pass runs at the copy rate on the bytes
+        # its kernels really move; profiles/r*/traffic_summary*.json, same kernel sources)
+        summ = pmc_summary(args) if world == 1 else None
+        if summ is not None:
+            tot = float(sum(v["hbm_bytes"] for v in summ["kernels"].values()))
+            res["box_normalised"] = {"traffic_bytes_per_pass": tot, "copy_GBs": copy_bw["copy_8B_per_lane_GBs"],
+                                     "pass_ms_at_copy_rate": tot / (copy_bw["copy_8B_per_lane_GBs"] * 1e9) * 1e3,
+                                     "pass_over_copy_floor": (elapsed / args.steps) / (tot / (copy_bw["copy_8B_per_lane_GBs"] * 1e9))}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w, args)
         print(json.dumps(res))

@@ -149,7 +149,7 @@ class EkfRunner:
             if P * int(n_regions) != B:
                 raise ValueError("the batch does not hold the same number of cost weights for every region")
             sd.R, sd.P = int(n_regions), P
-            if "on_front" not in res:
+            if "on_front" not in res or tuple(res["on_front"].shape) != (int(n_regions), P):
                 res["on_front"] = torch.empty((int(n_regions), P), dtype=torch.int32, device=dev)
                 res["i_opt"] = torch.empty((int(n_regions),), dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream(dev) if stream is None else stream

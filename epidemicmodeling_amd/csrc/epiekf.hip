@@ -843,6 +843,10 @@ struct Helper { hipStream_t stream = nullptr; hipEvent_t ev[kHelperEvents] = {};
 static std::mutex g_dev_mu;
 static std::atomic<int> g_simds[kMaxDevices];
 static std::vector<Helper *> g_helpers[kMaxDevices];
+// helpers that were forked into a caller's stream CAPTURE: such a stream stays in capture mode until the caller ends the
+// capture, which the library cannot see, so it is never leased again (another thread's hipEventRecord on it would fail or
+// invalidate that capture); kept here until epi_host_pool_release
+static std::vector<Helper *> g_retired_helpers[kMaxDevices];
 
 static int current_device()
 {
@@ -887,8 +891,14 @@ static hipError_t helper_acquire(int dev, Helper **out)
 }
 struct HelperLease {       // returns the helper to its device's idle list when the enqueueing call ends
     int dev; Helper *h = nullptr;
+    bool captured = false;  // the caller's stream is being captured: the helper joined that capture and is retired instead
     explicit HelperLease(int d) : dev(d) {}
-    ~HelperLease() { if (h) { std::lock_guard<std::mutex> lk(g_dev_mu); g_helpers[dev].push_back(h); } }
+    ~HelperLease()
+    {
+        if (!h) return;
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        (captured ? g_retired_helpers[dev] : g_helpers[dev]).push_back(h);
+    }
 };
 static void helpers_release_all()
 {
@@ -896,7 +906,12 @@ static void helpers_release_all()
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
     for (int dev = 0; dev < kMaxDevices; dev++) {
         std::vector<Helper *> mine;
-        { std::lock_guard<std::mutex> lk(g_dev_mu); mine.swap(g_helpers[dev]); }
+        {
+            std::lock_guard<std::mutex> lk(g_dev_mu);
+            mine.swap(g_helpers[dev]);
+            mine.insert(mine.end(), g_retired_helpers[dev].begin(), g_retired_helpers[dev].end());
+            g_retired_helpers[dev].clear();
+        }
         if (mine.empty()) continue;
         (void)hipSetDevice(dev);
         for (Helper *h : mine) helper_destroy(h);
@@ -1208,6 +1223,11 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
     //   * the sweep's scoring tail: the horizon's u_opt_smooth is final after the smoother's first T - 1 - t_hist steps,
     //     so the recursion is cut there and scoring + Pareto filter run beside the rest of it.
     HelperLease lease(L.dev);
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();    // the legacy default stream cannot be queried while another stream captures
+        lease.captured = cs != hipStreamCaptureStatusNone;
+    }
     if ((e = helper_acquire(L.dev, &lease.h)) != hipSuccess) return e;
     Helper *h = lease.h;
     int ne = 0;
@@ -1764,7 +1784,9 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     }
     if (o_rank != (size_t)-1) dout.pinv_rank = (int32_t *)(base + o_rank);
     if (o_stat != (size_t)-1) dout.status = (int32_t *)(base + o_stat);
-    if ((e = io.upload(cx, base)) != hipSuccess) return hip_fail(err, e, "upload");
+    // from here on copies that read the caller's arrays / the pinned buffer may be in flight: every error return waits
+    // for the stream first, so that neither is touched after the call has returned
+    if ((e = io.upload(cx, base)) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "upload"); }
     const int rc = epi_ekf_run_device(&d, &din, &dout, wsb ? base + o_ws : nullptr, wsb, cx->stream, err);
     if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
     if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download");
@@ -1837,7 +1859,13 @@ static void workers_release_all()
 // runs job(r) for r = 0 .. n-1 on the workers of devices dev_of(r) and waits for all of them
 static void run_on_devices(int n, const std::function<int(int)> &dev_of, const std::function<void(int)> &job)
 {
-    if (n == 1) { job(0); return; }          // one block: the calling thread does it
+    if (n == 1) {                            // one block: the calling thread does it, and keeps its current device
+        int prev = 0;
+        const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+        job(0);
+        if (have_prev) (void)hipSetDevice(prev);
+        return;
+    }
     std::mutex mu;
     std::condition_variable cv;
     int left = n;
@@ -1858,10 +1886,17 @@ int epi_ekf_run_host(const epi_batch_desc *d, const epi_inputs *in, const epi_ou
     int rc = host_args_ok(d, in, out, err);
     if (rc != EPI_OK) return rc;
     hipError_t e = hipSuccess;
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;       // the calling thread keeps its current device
     HostCtx *cx = ctx_acquire(device, &e);
-    if (!cx || e != hipSuccess) { if (cx) ctx_release(cx); return hip_fail(err, e, "hipSetDevice / context"); }
+    if (!cx || e != hipSuccess) {
+        if (cx) ctx_release(cx);
+        if (have_prev) (void)hipSetDevice(prev);
+        return hip_fail(err, e, "hipSetDevice / context");
+    }
     rc = run_host_block(cx, d, in, out, 0, d->B, err);
     ctx_release(cx);
+    if (have_prev) (void)hipSetDevice(prev);
     return rc;
 }
 
@@ -1970,12 +2005,13 @@ static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_
     hipError_t e = cx->reserve(io.off + 256);
     if (e != hipSuccess) return hip_fail(err, e, "device arena");
     char *base = cx->arena;
-    if ((e = io.upload(cx, base)) != hipSuccess) return hip_fail(err, e, "upload");
+    // (as in run_host_block: after upload() every error return waits for the stream)
+    if ((e = io.upload(cx, base)) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "upload"); }
     double *chain = (double *)(base + o_chain);
     int32_t *series = (int32_t *)(base + o_ser);
     hipLaunchKernelGGL(sweep_expand, dim3((unsigned)((Bd + 255) / 256), 8), dim3(256), 0, cx->stream, (int)nrows, Rd, (int)P,
                        (int)EPI_PRM_EPSILON, (const double *)(base + o_reg), (const double *)(base + o_eps), chain, series);
-    if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "sweep_expand launch");
+    if ((e = hipGetLastError()) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "sweep_expand launch"); }
     epi_inputs din{};
     din.x_series = series; din.u_series = series;
     din.x = (const double *)(base + o_x); din.u = (const double *)(base + o_u); din.R_series = (const double *)(base + o_rs);
@@ -2002,7 +2038,7 @@ static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_
         const size_t cnt = T * (size_t)g.rows * (size_t)Rd;
         hipLaunchKernelGGL(sweep_gather_opt, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, cx->stream, (int)T, g.rows, Rd, (int)P,
                            (int)blk, (int)nblk, (const int32_t *)(base + o_io), g.src, (double *)(base + g.off));
-        if ((e = hipGetLastError()) != hipSuccess) return hip_fail(err, e, "sweep_gather_opt launch");
+        if ((e = hipGetLastError()) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "sweep_gather_opt launch"); }
     }
     if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download");
     return EPI_OK;

@@ -159,26 +159,18 @@ def _zero_lag_ma(x, n):
     return y[pad:pad + x.shape[0]]
 
 
-def simulate_observations(regions, u_hist, seed: int = 2):
-    """SIalpha_Controlled.m semantics (noise-free), daily counts Poisson-thinned, then the
-    reference's preprocessing (TrainPredictPrescribeNPI.m:173-175,240).
-    Returns dict with x [T,R] (normalised smoothed new cases), R_v [T,R], I0 [R]."""
-    T, _, nR = u_hist.shape
-    N, a, b = regions["N"], regions["a"], regions["b"]
-    s = 1.0 - 100.0 / N
-    i = 100.0 / N
-    al = np.full(nR, ALPHA0)
-    lam = np.zeros((T, nR))
-    truth = np.zeros((T, 3, nR))
-    dt = 1.0
-    for t in range(T):
-        drive = np.einsum("rk,kr->r", MODEL_GAMMA * a, IP_MAXES[:, None] - u_hist[t])
-        sn = np.maximum(0.0, np.minimum(1.0, s - dt * (al * s * i)))
-        inn = np.maximum(0.0, np.minimum(1.0, i + dt * (al * s * i - MODEL_BETA * i)))
-        an = np.maximum(ALPHA_MIN, np.minimum(ALPHA_MAX, al + dt * (-MODEL_GAMMA * al + MODEL_GAMMA * b + drive)))
-        s, i, al = sn, inn, an
-        lam[t] = N * s * i * al
-        truth[t, 0], truth[t, 1], truth[t, 2] = s, i, al
+def _euler_step(s, i, al, a, b, u_t, dt=1.0):
+    """One noise-free day of SIalpha_Controlled.m:22-30 for all regions (a [R,12], u_t [12,R])."""
+    drive = np.einsum("rk,kr->r", MODEL_GAMMA * a, IP_MAXES[:, None] - u_t)
+    sn = np.maximum(0.0, np.minimum(1.0, s - dt * (al * s * i)))
+    inn = np.maximum(0.0, np.minimum(1.0, i + dt * (al * s * i - MODEL_BETA * i)))
+    an = np.maximum(ALPHA_MIN, np.minimum(ALPHA_MAX, al + dt * (-MODEL_GAMMA * al + MODEL_GAMMA * b + drive)))
+    return sn, inn, an
+
+
+def _observe(N, lam, truth, seed):
+    """Daily counts Poisson-thinned, then the reference's preprocessing (TrainPredictPrescribeNPI.m:173-175,240)."""
+    nR = N.shape[0]
     rng = np.random.Generator(np.random.Philox(seed))
     raw = rng.poisson(np.minimum(lam, 1e15)).astype(np.float64)
     smoothed = _causal_ma(raw, 7)
@@ -191,6 +183,81 @@ def simulate_observations(regions, u_hist, seed: int = 2):
         if nz.size:
             I0[r] = max(MIN_CASES, float(np.mean(smoothed[nz, r])))
     return {"x": x, "R_v": R_v, "I0": I0, "raw": raw, "truth": truth}
+
+
+def simulate_observations(regions, u_hist, seed: int = 2):
+    """SIalpha_Controlled.m semantics (noise-free) under the given NPI history, then _observe().
+    Returns dict with x [T,R] (normalised smoothed new cases), R_v [T,R], I0 [R]."""
+    T, _, nR = u_hist.shape
+    N, a, b = regions["N"], regions["a"], regions["b"]
+    s = 1.0 - 100.0 / N
+    i = 100.0 / N
+    al = np.full(nR, ALPHA0)
+    lam = np.zeros((T, nR))
+    truth = np.zeros((T, 3, nR))
+    for t in range(T):
+        s, i, al = _euler_step(s, i, al, a, b, u_hist[t])
+        lam[t] = N * s * i * al
+        truth[t, 0], truth[t, 1], truth[t, 2] = s, i, al
+    return _observe(N, lam, truth, seed)
+
+
+def make_live_regions(n_regions: int, seed: int = 20211104, region_offset: int = 0):
+    """make_regions() for an epidemic that can stay alive: in the trained table every b is 0 and for 124 of the 235
+    regions a' * u_max (the contact rate alpha settles at with every NPI lifted) is below the recovery rate beta, i.e.
+    the model's epidemic dies whatever the plan.  Regions whose a' * u_max is below 1.5-2.5 beta (drawn per region) get
+    `a` scaled up to that value, so that lifting NPIs makes the epidemic grow and imposing them makes it shrink -- the
+    trade-off the sweep of TrainPredictPrescribeNPI.m:421-460 exists for.  Directions of `a` (which NPI matters) stay
+    the trained ones."""
+    reg = make_regions(n_regions, region_offset=region_offset)
+    rng = np.random.Generator(np.random.Philox(seed + region_offset))
+    free = reg["a"] @ IP_MAXES
+    target = MODEL_BETA * rng.uniform(1.5, 2.5, n_regions)
+    scale = np.where(free < target, target / np.maximum(free, 1e-12), 1.0)
+    reg["a"] = reg["a"] * scale[:, None]
+    reg["a_scale"] = scale
+    return reg
+
+
+def simulate_reactive_epidemic(regions, T: int, seed: int = 11, obs_seed: int = 2, p_up: float = 0.3, p_dn: float = 0.3):
+    """A LIVING multi-wave epidemic: the same noise-free SIalpha_Controlled.m dynamics, but the NPI history REACTS to the
+    infected share instead of being drawn blindly (make_npi_history), the way real policy did: above `hi` the region
+    tightens (every day each NPI goes up one level with probability p_up, until the contact rate would settle at beta/2),
+    below `lo` it relaxes (down one level with probability p_dn -- 0.6 once i < lo/3 -- until the contact rate would
+    settle at 1.4-1.9 beta), in between it keeps its course.  lo = max(2e-5, 30/N) (a small region still reports cases on
+    most days), hi = 8 lo; i0 = min(100/N, lo/20) so that the first burst (alpha0 = beta + ln 2.5 decays with a 7-day
+    constant: ~100x) ends near hi instead of exhausting a small region.  Result on the 300 regions: 5-8 waves in 400
+    days, i(400) in [2e-6, 6e-3], s(400) >= 0.58, cases reported on >= 95 % of the days.
+    Returns (u_hist [T,12,R] piecewise-constant integer levels, observations dict as simulate_observations)."""
+    N, a, b = regions["N"], regions["a"], regions["b"]
+    nR = N.shape[0]
+    rng = np.random.Generator(np.random.Philox(seed))
+    relax_to = MODEL_BETA * rng.uniform(1.4, 1.9, nR)
+    lo = np.maximum(2e-5, 30.0 / N)
+    hi = 8.0 * lo
+    umax = IP_MAXES.astype(np.int64)[:, None]
+    settle = lambda cur: np.einsum("rk,kr->r", a, IP_MAXES[:, None] - cur)        # steady alpha of a plan (b = 0 aside)
+    cur = np.tile(umax, (1, nR))
+    for _ in range(200):                # start just tightened: down from the maximum until alpha would settle at beta/2
+        dn = (rng.random((NUM_NPI, nR)) < 0.2) & (settle(cur)[None] < 0.5 * MODEL_BETA)
+        cur = np.clip(cur - dn, 0, umax)
+    i = np.minimum(100.0 / N, lo / 20.0)
+    s = 1.0 - i
+    al = np.full(nR, ALPHA0)
+    mode = np.ones(nR, dtype=np.int64)
+    u = np.zeros((T, NUM_NPI, nR)); lam = np.zeros((T, nR)); truth = np.zeros((T, 3, nR))
+    for t in range(T):
+        mode = np.where(i > hi, 1, np.where(i < lo, 0, mode))
+        r = rng.random((NUM_NPI, nR))
+        st = settle(cur)
+        up = (mode[None] == 1) & (r < p_up) & (st[None] > 0.5 * MODEL_BETA)
+        dn = (mode[None] == 0) & (r < np.where(i < lo / 3.0, 0.6, p_dn)[None]) & (st[None] < relax_to[None])
+        cur = np.clip(cur + up.astype(np.int64) - dn.astype(np.int64), 0, umax)
+        u[t] = cur
+        s, i, al = _euler_step(s, i, al, a, b, u[t])
+        lam[t] = N * s * i * al
+        truth[t, 0], truth[t, 1], truth[t, 2] = s, i, al
+    return u, _observe(N, lam, truth, obs_seed)
 
 
 def _base_prm(B):
@@ -254,13 +321,23 @@ def epsilon_grid(n: int = 250) -> np.ndarray:
 
 
 def make_cfg4(n_regions: int = 300, n_eps: int = 250, T_hist: int = 400, horizon: int = 120,
-              region_offset: int = 0) -> Workload:
+              region_offset: int = 0, live: bool = False) -> Workload:
     """BASELINE config 4: SIAlphaModelEKFOptControlled Pareto sweep, regions x epsilon chains over
     T_hist observed days + `horizon` days with x = NaN and u = NaN (TrainPredictPrescribeNPI.m:421-460).
-    Chain c = r * n_eps + e shares region r's series."""
-    reg = make_regions(n_regions, region_offset=region_offset)
-    u_hist = make_npi_history(n_regions, T_hist, seed=1 + region_offset)
-    obs = simulate_observations(reg, u_hist, seed=2 + region_offset)
+    Chain c = r * n_eps + e shares region r's series.
+
+    live = False: the series SURVEY.md 8(d) specifies -- ONE wave from alpha0 = beta + ln 2.5 under a blindly drawn NPI
+    history; it is extinct long before day 400 (smoothed i(400) = 0, x = R_v = 0 on most days).
+    live = True ("cfg4-live"): the same shape and filter parameterisation on a living multi-wave epidemic
+    (make_live_regions + simulate_reactive_epidemic): what the reference runs the sweep on (real series,
+    TrainPredictPrescribeNPI.m:97-198)."""
+    if live:
+        reg = make_live_regions(n_regions, region_offset=region_offset)
+        u_hist, obs = simulate_reactive_epidemic(reg, T_hist, seed=11 + region_offset, obs_seed=2 + region_offset)
+    else:
+        reg = make_regions(n_regions, region_offset=region_offset)
+        u_hist = make_npi_history(n_regions, T_hist, seed=1 + region_offset)
+        obs = simulate_observations(reg, u_hist, seed=2 + region_offset)
     T = T_hist + horizon
     x = np.concatenate([obs["x"], np.full((horizon, n_regions), np.nan)], axis=0)
     u = np.concatenate([u_hist, np.full((horizon, NUM_NPI, n_regions), np.nan)], axis=0)
@@ -296,8 +373,8 @@ def make_cfg4(n_regions: int = 300, n_eps: int = 250, T_hist: int = 400, horizon
                     u=np.ascontiguousarray(u), R_series=np.ascontiguousarray(Rv), R_scalar=None,
                     x_series=rr.astype(np.int32), u_series=rr.astype(np.int32), prm=prm, s_init=s_init, Ps_init=P0,
                     s_final=s_final, Ps_final=Ps_final, Q=Q,
-                    meta={"workload": "cfg4", "regions": n_regions, "n_eps": n_eps, "T_hist": T_hist,
-                          "horizon": horizon, "truth_end": obs["truth"][-1][:, rr]})
+                    meta={"workload": "cfg4-live" if live else "cfg4", "regions": n_regions, "n_eps": n_eps, "T_hist": T_hist,
+                          "horizon": horizon, "truth_end": obs["truth"][-1][:, rr], "truth": obs["truth"]})
 
 
 def make_cfg5(n_regions: int = 300, n_draws: int = 1024, T: int = 400, seed: int = 5) -> Workload:

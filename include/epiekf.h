@@ -38,7 +38,9 @@
  * several threads at once; all device work of a *_device call is enqueued on
  * the caller's stream (stages that are off the critical path run on a helper
  * stream that is forked from and joined back into the caller's stream, so the
- * call behaves like work on that one stream, also under stream capture).
+ * call behaves like work on that one stream, also under stream capture: a
+ * helper stream that joined a caller's capture is not handed to any other call
+ * afterwards -- it is retired until epi_host_pool_release()).
  * What the library keeps between calls, all of it freed by
  * epi_host_pool_release(): the CU count of each device it has seen, idle
  * helper streams (one per concurrent call and device, with their events), and

@@ -4,7 +4,9 @@ The reference (MATLAB) cannot run in the build image and ships no golden vectors
 (SURVEY.md 4 / 8c), so the vectors are produced by the repo's two independent restatements of the
 .m sources: outputs come from oracle/ekf_oracle.c, and generation FAILS unless oracle/ekf_numpy.py
 (LAPACK pinv / LU) agrees with it on every chain (forward quantities <= 1e-9 relative, identical pinv
-truncation ranks).  Only data is stored: inputs and expected outputs.
+truncation ranks) AND the smoothed epidemic states lie within 1e-5 of the reference's formulas evaluated
+in 160-digit arithmetic (oracle/referee_mp.py) and no further from them than ten times the LAPACK
+reading is.  Only data is stored: inputs and expected outputs.
 
     python tests/golden/make_golden.py
 """
@@ -18,6 +20,7 @@ sys.path.insert(0, ROOT)
 
 from epidemicmodeling_amd import synth  # noqa: E402
 from tests import helpers as H  # noqa: E402
+from oracle import referee_mp as rf  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 FWD = ["u_opt", "S_MINUS", "S_PLUS", "P_MINUS", "P_PLUS", "K_GAIN", "innovations", "rho"]
@@ -49,7 +52,7 @@ def main():
         w = mk()
         ob = H.oracle_batch(w)
         names = [n for n in H.OUT_NAMES if not (w.model.startswith("NewCase") and n == "u_opt_smooth")]
-        worst_smooth = 0.0
+        worst_smooth = worst_c = worst_l = 0.0
         for c in range(w.B):
             nd = H.numpy_chain(w, c)
             for n in FWD:
@@ -58,21 +61,30 @@ def main():
             if "pinv_rank" in nd:
                 assert np.array_equal(nd["pinv_rank"], ob["pinv_rank"][:, c]), (name, c, "pinv rank")
             # smoothed states: conditioned by pinv of matrices with cond up to 1e60 whose kept singular
-            # values sit just above MATLAB's cut-off -- two SVD implementations agree on the truncation
-            # rank but not on those values' trailing digits, so the gate is loose and the measured
-            # disagreement is stored with the fixture (meta_smooth_disagreement)
+            # values sit just above MATLAB's cut-off -- two fp64 SVD implementations agree on the truncation
+            # rank but not on those values' trailing digits (their disagreement is stored with the fixture,
+            # meta_smooth_disagreement).  What decides is the referee: the exact evaluation of the reference's
+            # formulas.  Round 3 accepted 5e-2 between the two fp64 readings here; measured against the
+            # referee the C oracle is within 3e-12 ... 1e-6 on every fixture (the 1e-6 is the time-flipped
+            # 6-state wrapper, whose FORWARD map is unstable) and the LAPACK reading within 2e-15 ... 3e-4.
             e = H.rowwise_abs_rel_err(H.batch_chain(ob, "S_SMOOTH", c, w.m)[:3], nd["S_SMOOTH"][:3])
             worst_smooth = max(worst_smooth, e)
-            assert e <= 5e-2, (name, c, "S_SMOOTH", e)
+            ex = rf.run_model(w.model, *H.chain_args(w, c))
+            ec = H.rowwise_abs_rel_err(H.batch_chain(ob, "S_SMOOTH", c, w.m)[:3], ex["S_SMOOTH"][:3])
+            el = H.rowwise_abs_rel_err(nd["S_SMOOTH"][:3], ex["S_SMOOTH"][:3])
+            worst_c, worst_l = max(worst_c, ec), max(worst_l, el)
+            assert ec <= 1e-5 and ec <= 10.0 * el + 1e-12, (name, c, "S_SMOOTH vs the exact evaluation", ec, el)
         out = pack_inputs(w)
         out["meta_smooth_disagreement"] = worst_smooth
+        out["meta_smooth_distance_from_exact_C"] = worst_c
+        out["meta_smooth_distance_from_exact_lapack"] = worst_l
         for n in names:
             out["out_" + n] = ob[n]
         out["out_pinv_rank"] = ob["pinv_rank"]
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(f"{name}: B={w.B} T={w.T} -> {os.path.getsize(path) / 1024:.0f} KiB; "
-              f"C-vs-NumPy smoothed-state disagreement {worst_smooth:.1e}")
+              f"C-vs-NumPy smoothed-state disagreement {worst_smooth:.1e}; from the exact evaluation: C {worst_c:.1e}, LAPACK {worst_l:.1e}")
 
 
 if __name__ == "__main__":

@@ -229,3 +229,83 @@ def host_call(w, devices=None, outputs=None, extras=True, shape=0):
         rc = _lib.lib().epi_ekf_run_host_multi(C.byref(d), C.byref(ins), C.byref(outs), len(devices), ids, err)
     _lib.check(rc, err)
     return out
+
+
+REFEREE_CASES = ["ref_cfg4_dead_400_120", "ref_cfg4_live_400_120", "ref_cfg4_live_60_120", "ref_row3_adaptiveR_30_120",
+                 "ref_cfg3_400", "ref_sia3_backward_120", "ref_sia6_backward_40", "ref_newcase_sweep_400_120"]
+REFEREE_GATE_CAP = 1e-2      # an output whose frozen gate exceeds this is rounding-dominated in fp64: reported, not gated
+
+
+def load_referee(name):
+    """tests/golden/<name>.npz (tests/golden/make_golden_referee.py) -> (Workload, dict): `ref_*` the reference's formulas
+    in 160-digit arithmetic rounded once (MATLAB shapes + a trailing chain axis), `lap_*` the frozen LAPACK reading,
+    `dist_C_* / dist_lap_* / tol_*` the distances measured when the fixture was frozen and the gates derived from them."""
+    w, _ = load_golden(name)
+    d = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    return w, {k: d[k] for k in d.files if not k.startswith("in_")}
+
+
+def referee_compare(w, got, fx, what):
+    """Outputs `got` (batched [T][rows][B] arrays of the chains of fixture `fx`) against the frozen referee and LAPACK
+    vectors.  Returns (failures, report): every output whose frozen gate is <= REFEREE_GATE_CAP must lie within the gate
+    of the exact result and within 2 x the gate of the LAPACK reading; pinv ranks must equal the exact ranks outside the
+    steps the referee lists as ambiguous (a singular value within 10 x of the cut-off); where the smoothed costates are
+    rounding-dominated the free controls may differ from the exact plan in no more entries than the LAPACK reading's did."""
+    m, B = w.m, w.B
+    fails, rep = [], {}
+    rows = lambda a: a[None] if a.ndim == 1 else a.reshape(-1, a.shape[-1])
+    for key in sorted(k for k in fx if k.startswith("ref_")):
+        n = key[4:]
+        if n in ("pinv_rank", "near_cutoff"):
+            continue
+        diag = n.endswith("_diag")
+        base = n[:-5] if diag else n
+        if base not in got:
+            continue
+        worst, worst_lap = 0.0, 0.0
+        for c in range(B):
+            g = batch_chain(got, base, c, m)
+            if diag:
+                g = np.stack([g[i, i] for i in range(m)])
+            worst = max(worst, rowwise_abs_rel_err(rows(g), rows(fx[key][..., c])))
+            if "lap_" + n in fx:
+                worst_lap = max(worst_lap, rowwise_abs_rel_err(rows(g), rows(fx["lap_" + n][..., c])))
+        tol = float(fx["tol_" + base])
+        gated = tol <= REFEREE_GATE_CAP
+        rep[n] = {"vs_exact": worst, "vs_lapack_reading": worst_lap if "lap_" + n in fx else None, "gate": tol if gated else None,
+                  "frozen_distance_C": float(fx["dist_C_" + base]), "frozen_distance_lapack": float(fx["dist_lap_" + base])}
+        if gated and not worst <= tol:
+            fails.append((what, n, "vs exact", worst, tol))
+        if gated and "lap_" + n in fx and not worst_lap <= 2.0 * tol:
+            fails.append((what, n, "vs LAPACK reading", worst_lap, 2.0 * tol))
+    # the epidemic states of S_SMOOTH have a gate of their own (the costates beside them may be rounding-dominated)
+    if "ref_S_SMOOTH" in fx and "S_SMOOTH" in got:
+        worst = max(rowwise_abs_rel_err(batch_chain(got, "S_SMOOTH", c, m)[:3], fx["ref_S_SMOOTH"][:3, :, c]) for c in range(B))
+        tol = float(fx["tol_S_SMOOTH_states"])
+        rep["S_SMOOTH_states"] = {"vs_exact": worst, "gate": tol}
+        if not worst <= tol:
+            fails.append((what, "S_SMOOTH(1:3)", "vs exact", worst, tol))
+    if "ref_pinv_rank" in fx and "pinv_rank" in got:
+        T = w.T
+        amb = {(int(c), (T - 1 - int(k)) if "Backward" in w.model else int(k)) for c, k, _ in fx["ref_near_cutoff"]}
+        mm = [(c, int(k)) for c in range(B) for k in np.flatnonzero(got["pinv_rank"][:, c] != fx["ref_pinv_rank"][:, c])]
+        out = [x for x in mm if x not in amb]
+        rep["pinv_rank"] = {"mismatch_steps": len(mm), "outside_ambiguous_steps": len(out), "ambiguous_steps": len(amb)}
+        if out:
+            fails.append((what, "pinv_rank", "differs from the exact rank away from the cut-off", out[:5], 0))
+    if "flips_lap" in fx and "u_opt_smooth" in got:
+        flips = []
+        for c in range(B):
+            su = int(w.u_series[c]) if w.u_series is not None else c
+            fm = np.isnan(w.u[:, :, su].T)
+            fm[:, 0 if "Backward" in w.model else -1] = False
+            flips.append(int(np.sum(batch_chain(got, "u_opt_smooth", c, m)[fm] != fx["ref_u_opt_smooth"][..., c][fm])))
+        rep["control_flips_vs_exact"] = {"this": flips, "frozen_C": fx["flips_C"].tolist(), "frozen_lapack": fx["flips_lap"].tolist(),
+                                         "free_controls": fx["free_controls"].tolist()}
+        if float(fx["tol_u_opt_smooth"]) <= REFEREE_GATE_CAP:
+            if sum(flips) != 0:
+                fails.append((what, "u_opt_smooth", "differs from the exact plan", sum(flips), 0))
+        elif sum(flips) > max(int(fx["flips_lap"].sum()), int(fx["flips_C"].sum())):
+            fails.append((what, "u_opt_smooth", "more flips vs the exact plan than either frozen fp64 reading", sum(flips),
+                          max(int(fx["flips_lap"].sum()), int(fx["flips_C"].sum()))))
+    return fails, rep
