@@ -332,8 +332,11 @@ def main():
     torch.cuda.synchronize(dev)
     if score:
         prepare_scoring()
+    # EPI_BENCH_STAGED=1: every pass -- warm-up included -- is enqueued stage by stage, so that a `rocprofv3 --stats` of the run
+    # sees ONE kind of launch per kernel and its averages are the per-kernel durations `roofline` quotes
+    staged = os.environ.get("EPI_BENCH_STAGED") == "1"
     for _ in range(args.warmup):
-        one_step()
+        one_step([torch.cuda.Event(enable_timing=True) for _ in range(4)] if staged else None)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -343,7 +346,6 @@ def main():
     # the forward pass's time segments).  The per-kernel durations come from K further passes enqueued stage by stage, each
     # bracketed by HIP events on the launch stream.  EPI_BENCH_STAGED=1: time the staged passes instead (round-1 behaviour).
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    staged = os.environ.get("EPI_BENCH_STAGED") == "1"
     gather_log["on"] = True
     t0 = time.perf_counter()
     for k in range(args.steps):

@@ -62,7 +62,7 @@ class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
     def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, time_pipe=0, precheck=True, lane_block=0, shape=0,
-                 storage="f64"):
+                 storage="f64", exact_nonfinite=False):
         """time_pipe: epi_batch_desc.time_pipe (0 = the library decides whether a full call runs its forward kernel in time
         segments with the pinv grid of each segment beside the next, 1 = on, -1 = off).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
@@ -78,9 +78,12 @@ class EkfRunner:
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
                                    dw.r_mode, self.mask, dw.q_mode)
         # epi_batch_desc.shape: 0 = by batch size, 1 / 2 = one / four lanes per chain (6-state generic models)
-        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2}.get(shape, shape)
+        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2, "wave": 3}.get(shape, shape)
         # epi_batch_desc.storage: "f32" = outputs stored as float32 (each the fp64 result rounded once; BASELINE config 5)
         self.desc.storage = {"f64": 0, "f32": 1}[storage]
+        # epi_batch_desc.exact_nonfinite: chains whose covariance overflows are run again by the dense kernels, in place
+        # (their Inf / NaN pattern is then the dense evaluation's, i.e. the reference's)
+        self.desc.exact_nonfinite = int(bool(exact_nonfinite))
         odt = torch.float32 if storage == "f32" else torch.float64
         if lane_block == "auto":       # one block per wavefront of the launch
             lane_block = int(_lib.lib().epi_ekf_preferred_lane_block(C.byref(self.desc)))
@@ -184,10 +187,12 @@ class EkfRunner:
         return sum(t.numel() * t.element_size() for t in self.out.values())
 
 
-def run_workload(w, outputs=None, device="cuda:0", extras=True, time_pipe=0, precheck=True, lane_block=0, shape=0, storage="f64"):
+def run_workload(w, outputs=None, device="cuda:0", extras=True, time_pipe=0, precheck=True, lane_block=0, shape=0, storage="f64",
+                 exact_nonfinite=False):
     """Convenience: upload `w`, run once, return dict name -> numpy array [T, rows, B] (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
-    r = EkfRunner(dw, outputs, extras=extras, time_pipe=time_pipe, precheck=precheck, lane_block=lane_block, shape=shape, storage=storage)
+    r = EkfRunner(dw, outputs, extras=extras, time_pipe=time_pipe, precheck=precheck, lane_block=lane_block, shape=shape, storage=storage,
+                  exact_nonfinite=exact_nonfinite)
     r.run()
     torch.cuda.synchronize(dw.device)
     res = {n: r.unblocked(n).cpu().numpy() for n in r.out}

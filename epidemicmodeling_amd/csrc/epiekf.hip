@@ -66,6 +66,7 @@ struct KArgs {
     // bound by HBM / per-CU memory throughput, which scales with active lanes, not by wave count.
     int lw;
     int quad;   // 6-state generic models: four lanes per chain (ekf_quad.hpp) instead of one
+    int wave;   // 6-state generic models: one WAVEFRONT per chain (ekf_wave.hpp)
     // epi_batch_desc.storage = 1: the caller's outputs are fp32 arrays (same layouts, 4-byte elements); each selected
     // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
     // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
@@ -79,6 +80,11 @@ struct KArgs {
     double *hand_s, *hand_p;
     int32_t *hand_i;
     int hand_pitch;       // Bp: chains the hand-over rows are sized for
+    // epi_batch_desc.exact_nonfinite: after the packed kernels, chains whose covariance went non-finite (status bit 0) are
+    // run again by the dense kernels, in place.  `only` [B] (workspace): the dense fwd / pinv / bwd launches of that second
+    // pass return at once for every chain whose word is 0; only[B] counts the marked chains
+    const int32_t *only;
+    int32_t *only_buf;
     int mon_defer;   // 1: this launch does not enqueue ekf_monitor itself (the caller does, later)
     int mon_hoist;   // 1: the packed / quad forward kernels skip the innovation monitor, ekf_monitor replays it (r_mode 1)
     struct F32 { float *u_opt, *u_opt_smooth, *S_MINUS, *S_PLUS, *S_SMOOTH, *P_MINUS, *P_PLUS, *P_SMOOTH, *K_GAIN, *innovations, *rho; } f;
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd(const KArgs a)
     const int lane = threadIdx.x;
     const int c = a.c0 + blockIdx.x * a.lw + lane;
     if (lane >= a.lw || c >= a.c0 + a.cn) return;
+    if (a.only && !a.only[c]) return;             // second pass over the chains whose covariance went non-finite
     const int B = a.B, T = a.T, L = a.L;
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
     const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)blockIdx.y;
     const int c = a.c0 + cl;
+    if (a.only && !a.only[c]) return;
     const Lay lay = make_lay(a, c);
     constexpr int NSX = M * (M + 1) / 2;
     double Pu[NSX];
@@ -504,6 +512,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
     if (a.dense_flag && !*a.dense_flag) return;   // eks_bwd_sym handles this batch
     const int c = a.c0 + blockIdx.x * a.lw + threadIdx.x;
     if ((int)threadIdx.x >= a.lw || c >= a.c0 + a.cn) return;
+    if (a.only && !a.only[c]) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
@@ -642,6 +651,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 
 #include "ekf_sym.hpp"
 #include "ekf_quad.hpp"
+#include "ekf_wave.hpp"
 
 // ---------------------------------------------------------------------------
 // forward simulators
@@ -695,10 +705,12 @@ __global__ __launch_bounds__(256) void sialpha_sim(const epi_sim_desc d, const i
                                                    double *__restrict__ io, double *__restrict__ ao,
                                                    double *__restrict__ J0, double *__restrict__ J1,
                                                    const double *__restrict__ J0_prefix,
-                                                   const double *__restrict__ J1_prefix)
+                                                   const double *__restrict__ J1_prefix,
+                                                   const int32_t *__restrict__ gate)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.B) return;
+    if (gate && *gate == 0) return;       // second scoring pass after the dense re-run: nothing was re-run
     const int B = d.B;
     const int su = u_series ? u_series[c] : c;
     SimPrm p;
@@ -807,6 +819,17 @@ __global__ __launch_bounds__(256) void calib_copy_f64(const double *__restrict__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
+// epi_batch_desc.exact_nonfinite: only[c] = status bit 0 of chain c (the non-finite guard of GenericEKF.m:211 fired: its
+// covariance overflowed at some day), only[B] = how many chains that is
+__global__ __launch_bounds__(256) void mark_nonfinite(const int32_t *__restrict__ status, int32_t *__restrict__ only, int B)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= B) return;
+    const int v = status[c] & 1;
+    only[c] = v;
+    if (v) atomicAdd(only + B, 1);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -822,7 +845,7 @@ static int hip_fail(char *err, hipError_t e, const char *what)
     return EPI_ERR_HIP;
 }
 
-struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, innov, hand_s, hand_p, hand_i, total; };
+struct WsLayout { size_t s_minus, s_plus, p_minus, p_plus, x, rank, flag, innov, hand_s, hand_p, hand_i, only, status, total; };
 static int lane_block_of(const epi_batch_desc *d) { return (d->lane_block <= 0 || d->lane_block >= d->B) ? d->B : d->lane_block; }
 static size_t padded_chains(const epi_batch_desc *d)
 {
@@ -931,11 +954,17 @@ static bool monitor_hoisted(const epi_batch_desc *d)
 // per-day latency is what counts and the quad kernels' instruction stream is half as long (9 375 chains: 3.5 instead of
 // 6.1 ms per pass); beyond that the quad waves (one per SIMD at ~290 registers) would run in rounds and one lane per
 // chain, the shape with the least total work, wins (18 750 chains: 6.1 against 8.4 ms).  profiles/r02/batch_size_sweep.txt.
+// Round 4: one WAVEFRONT per chain (ekf_wave.hpp) while every chain can have a SIMD of its own (B <= 1024 on MI355X): a lone
+// wave's day costs ~0.6 us there against 2.1-2.2 us for a quad wave, at ~4 x the quad shape's total VALU work.  It needs the
+// innovation monitor as its own kernel (R_v a per-day series) and a fixed Q_w; otherwise four lanes per chain.
 static int shape_of(const epi_batch_desc *d, int dev)
 {
     const ModelInfo &mi = MODEL_TABLE[d->model];
     if (mi.m != 6 || !mi.generic || d->storage) return EPI_SHAPE_LANE;
+    const bool wave_ok = monitor_hoisted(d);
+    if (d->shape == EPI_SHAPE_WAVE) return wave_ok ? EPI_SHAPE_WAVE : EPI_SHAPE_QUAD;
     if (d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_LANE) return d->shape;
+    if (wave_ok && (long)d->B <= (long)simd_count(dev)) return EPI_SHAPE_WAVE;
     return ((long)d->B + kQC - 1) / kQC <= (long)simd_count(dev) ? EPI_SHAPE_QUAD : EPI_SHAPE_LANE;
 }
 
@@ -964,6 +993,10 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.hand_s = take(generic, (size_t)m * Bp * sizeof(double));
     w.hand_p = take(generic, (size_t)m * m * Bp * sizeof(double));
     w.hand_i = take(generic, Bp * sizeof(int32_t));
+    // exact_nonfinite: the per-chain mask of the dense second pass (+ its counter) and a status array of the library's own
+    // (the caller need not pass one)
+    w.only = take(generic && d->exact_nonfinite, (Bp + 1) * sizeof(int32_t));
+    w.status = take(generic && d->exact_nonfinite, Bp * sizeof(int32_t));
     w.total = off;
     return w;
 }
@@ -1004,6 +1037,7 @@ struct Launch {
     int dev, phase, hint, time_pipe;
     bool smooth;
     const Tail *tail;
+    bool rerun;      // epi_batch_desc.exact_nonfinite: dense second pass over the chains whose covariance went non-finite
 };
 
 // the innovation monitor as its own launch (after the forward kernel that wrote the innovations)
@@ -1038,7 +1072,14 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
     if (run_sym) {
         bool done = false;
         if constexpr (M == 6 && GENERIC) {
-            if (ka.quad) {
+            if (ka.wave) {          // one wavefront per chain (ekf_wave.hpp)
+                hipLaunchKernelGGL((ekf_fwd_wave<FLIP>), dim3((unsigned)ka.B), dim3(kWave), 0, st, ka, ka.dense_flag);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                done = true;
+            }
+        }
+        if constexpr (M == 6 && GENERIC) {
+            if (ka.quad && !done) {
                 // four lanes per chain, 16 chains per wavefront (ekf_quad.hpp): the specialisation for the layout and the
                 // window length this shape is meant for, or the general one
                 const int qblocks = (ka.B + kQC - 1) / kQC;
@@ -1113,7 +1154,13 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
     if (run_sym) {
         bool done = false;
         if constexpr (M == 6 && GENERIC) {
-            if (ka.quad) {
+            if (ka.wave) {
+                hipLaunchKernelGGL((eks_bwd_wave<FLIP>), dim3((unsigned)ka.B), dim3(kWave), 0, st, ka, ka.dense_flag);
+                done = true;
+            }
+        }
+        if constexpr (M == 6 && GENERIC) {
+            if (ka.quad && !done) {
                 const int qblocks = (ka.B + kQC - 1) / kQC;
                 if (ka.blk == kQC) hipLaunchKernelGGL((eks_bwd_quad<FLIP, kQC>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                 else hipLaunchKernelGGL((eks_bwd_quad<FLIP, 0>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
@@ -1135,7 +1182,7 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
 
 // scoring of the sweep's horizon (TrainPredictPrescribeNPI.m:481-493) from the u_opt_smooth the smoother just wrote,
 // then the Pareto filter and optimum per region (:624-633) when the call holds whole regions
-static hipError_t enqueue_tail(const KArgs &ka, const Tail &t, hipStream_t st)
+static hipError_t enqueue_tail(const KArgs &ka, const Tail &t, hipStream_t st, const int32_t *gate = nullptr)
 {
     epi_sim_desc sd{};
     sd.abi_version = EPIEKF_ABI_VERSION; sd.B = ka.B; sd.K = ka.T - t.t_hist; sd.Su = ka.B; sd.n_npi = ka.n_npi;
@@ -1144,10 +1191,10 @@ static hipError_t enqueue_tail(const KArgs &ka, const Tail &t, hipStream_t st)
     const double *u_h = ka.u_opt_smooth + (size_t)t.t_hist * ka.n_npi * ((size_t)ka.nblk * ka.blk);
     hipLaunchKernelGGL(sialpha_sim, dim3((ka.B + 255) / 256), dim3(256), 0, st, sd, (const int32_t *)nullptr, u_h, t.sp,
                        (const double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, t.J0, t.J1,
-                       t.J0_prefix, t.J1_prefix);
+                       t.J0_prefix, t.J1_prefix, gate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (!t.on_front && !t.i_opt)) return e;
-    hipLaunchKernelGGL(pareto_front, dim3(t.R), dim3(256), (size_t)2 * t.P * sizeof(double), st, t.P, t.J0, t.J1, t.on_front, t.i_opt);
+    hipLaunchKernelGGL(pareto_front, dim3(t.R), dim3(256), (size_t)2 * t.P * sizeof(double), st, t.P, t.J0, t.J1, t.on_front, t.i_opt, gate);
     return hipGetLastError();
 }
 
@@ -1161,6 +1208,32 @@ static hipError_t enqueue_tail(const KArgs &ka, const Tail &t, hipStream_t st)
 #endif
 constexpr int kTimeCuts[] = {EPI_TIME_CUTS};
 constexpr int kTimeSeg = (int)(sizeof(kTimeCuts) / sizeof(kTimeCuts[0])) - 1;
+
+// epi_batch_desc.exact_nonfinite.  The packed / quad kernels skip products with structural zeros, which is exact for finite
+// operands; once a chain's covariance has overflowed, a skipped `Inf * 0` leaves a finite number where the dense evaluation
+// (the reference's, and MATLAB's BLAS) has NaN.  Up to the first overflow both evaluations hold the same bits, so the
+// non-finite guard of :211 fires for such a chain in either (status bit 0).  Those chains -- and only those -- are run again
+// from the start by the dense kernels, which mirror the reference term for term, writing over their outputs in place; then
+// the scoring tail is repeated if any chain was re-run.  Costs three launches that return at once when no chain is marked
+// (the pinv grid's ~(B/64)(T-1) empty workgroups: ~0.15 ms at 75 000 x 520).
+template <int M, int FLIP>
+static hipError_t rerun_nonfinite_dense(const KArgs &ka, const Launch &L, hipStream_t st)
+{
+    hipError_t e = hipMemsetAsync(ka.only_buf + ka.B, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mark_nonfinite, dim3((ka.B + 255) / 256), dim3(256), 0, st, (const int32_t *)ka.status, ka.only_buf, ka.B);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    KArgs kd = ka;
+    kd.only = ka.only_buf; kd.dense_flag = nullptr; kd.quad = 0; kd.mon_hoist = 0;
+    kd.k_begin = 0; kd.k_end = 0; kd.bk_from = ka.T - 2; kd.bk_to = 0;
+    Launch Ld = L;
+    Ld.hint = 2; Ld.tail = nullptr;
+    if ((e = enqueue_fwd<M, FLIP, 1>(kd, Ld, st)) != hipSuccess) return e;
+    if ((e = enqueue_pinv<M>(kd, 0, ka.T - 1, st)) != hipSuccess) return e;
+    if ((e = enqueue_bwd<M, FLIP, 1>(kd, Ld, st)) != hipSuccess) return e;
+    if (L.tail) e = enqueue_tail(ka, *L.tail, st, ka.only_buf + ka.B);
+    return e;
+}
 
 template <int M, int FLIP, int GENERIC>
 static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
@@ -1210,6 +1283,9 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
             if ((e = enqueue_bwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         }
         if (phase == 0 && L.tail) e = enqueue_tail(ka, *L.tail, st);
+        if constexpr (GENERIC) {
+            if (e == hipSuccess && L.rerun && phase == 0 && L.hint != 2) e = rerun_nonfinite_dense<M, FLIP>(ka, L, st);
+        }
         return e;
     }
 
@@ -1238,8 +1314,9 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         return ee;
     };
     const long fwd_waves = ka.quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
+    // (one wavefront per chain: the pinv grid of so few chains takes ~30 us, nothing to pipeline -- unless asked for)
     const bool tp = ka.mon_hoist && !ka.stor && T >= 128 && L.time_pipe >= 0 &&
-                    (L.time_pipe == 1 || fwd_waves * 4 <= (long)simd_count(L.dev) * 3);
+                    (L.time_pipe == 1 || (!ka.wave && fwd_waves * 4 <= (long)simd_count(L.dev) * 3));
     bool helper_busy = false;
     if (tp) {
         for (int sg = 0; sg < kTimeSeg; sg++) {
@@ -1265,7 +1342,7 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         if ((e = launch_monitor<FLIP>(ka, L.dev, h->stream)) != hipSuccess) return e;
         helper_busy = true;
     }
-    if (L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2) {
+    if (L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2 && !ka.wave) {
         KArgs kb = ka;
         kb.bk_from = T - 2; kb.bk_to = L.tail->t_hist;              // the horizon days
         if ((e = enqueue_bwd<M, FLIP, GENERIC>(kb, L, st)) != hipSuccess) return e;
@@ -1279,6 +1356,9 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         if (L.tail && (e = enqueue_tail(ka, *L.tail, st)) != hipSuccess) return e;
     }
     if (helper_busy) e = fork(h->stream, st);
+    if constexpr (GENERIC) {
+        if (e == hipSuccess && L.rerun) e = rerun_nonfinite_dense<M, FLIP>(ka, L, st);
+    }
     return e;
 }
 
@@ -1335,8 +1415,9 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
     if (d->time_pipe < -1 || d->time_pipe > 1) { set_err(err, "time_pipe must be -1 (off), 0 (auto) or 1 (on)"); return EPI_ERR_BAD_ARG; }
     if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
-    if (d->shape < 0 || d->shape > 2) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain) or 2 (four lanes per chain)"); return EPI_ERR_BAD_ARG; }
+    if (d->shape < 0 || d->shape > 3) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain), 2 (four lanes per chain) or 3 (one wavefront per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
+    if (d->exact_nonfinite < 0 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 or 1"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
@@ -1356,7 +1437,8 @@ int epi_ekf_preferred_lane_block(const epi_batch_desc *d)
     if (epi_ekf_validate(&probe, nullptr) != EPI_OK) return 0;
     const ModelInfo &mi = MODEL_TABLE[d->model];
     const int dev = current_device();
-    const int lw = shape_of(d, dev) == EPI_SHAPE_QUAD ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2, dev);
+    const int sh = shape_of(d, dev);
+    const int lw = sh == EPI_SHAPE_WAVE ? 1 : (sh == EPI_SHAPE_QUAD ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2, dev));
     return lw < d->B ? lw : d->B;
 }
 
@@ -1395,6 +1477,7 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     ka.blk = lane_block_of(d); ka.nblk = (d->B + ka.blk - 1) / ka.blk;
     const int dev = current_device();
     ka.quad = shape_of(d, dev) == EPI_SHAPE_QUAD ? 1 : 0;
+    ka.wave = shape_of(d, dev) == EPI_SHAPE_WAVE ? 1 : 0;
     ka.stor = f32 ? 1 : 0;
     ka.bk_from = d->T - 2; ka.bk_to = 0;
     ka.c0 = 0; ka.cn = d->B;
@@ -1432,6 +1515,11 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     ka.f.K_GAIN = sel32(EPI_OUT_K_GAIN, out->K_GAIN); ka.f.innovations = sel32(EPI_OUT_INNOVATIONS, out->innovations);
     ka.f.rho = sel32(EPI_OUT_RHO, out->rho);
     ka.pinv_rank = out->pinv_rank; ka.status = out->status;
+    const bool rerun = mi.generic && d->exact_nonfinite != 0 && d->q_mode == 0 && d->phase == 0 && !f32;
+    if (mi.generic && d->exact_nonfinite) {
+        ka.only_buf = (int32_t *)(ws + wl.only);
+        if (!ka.status && rerun) ka.status = (int32_t *)(ws + wl.status);
+    }
     ka.mon_hoist = monitor_hoisted(d) ? 1 : 0;
     if (ka.mon_hoist && !ka.innovations && (ka.rho || ka.f.rho)) ka.innovations = (double *)(ws + wl.innov);
     ka.X = mi.generic ? (double *)(ws + wl.x) : nullptr;
@@ -1453,11 +1541,12 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
             if (((om | om32) & q.bit) && !q.p) { char b[128]; snprintf(b, sizeof b, "output %s selected but NULL", q.n); set_err(err, b); return EPI_ERR_BAD_ARG; }
         if (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH) && !out->u_opt_smooth) { set_err(err, "output u_opt_smooth selected but NULL"); return EPI_ERR_BAD_ARG; }
     }
+    // (exact_nonfinite needs the smoother's guard to find the chains: it runs the smoother whatever is selected)
     const bool smooth = ((om | om32) & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH)) ||
-                        out->pinv_rank || out->status;
+                        out->pinv_rank || out->status || rerun;
     hipStream_t st = (hipStream_t)stream;
     Launch L{};
-    L.dev = dev; L.phase = d->phase; L.time_pipe = d->time_pipe; L.smooth = smooth; L.tail = tail;
+    L.dev = dev; L.phase = d->phase; L.time_pipe = d->time_pipe; L.smooth = smooth; L.tail = tail; L.rerun = rerun;
     // a time-varying Q_w is read per step by the dense kernels only
     L.hint = (mi.generic && d->q_mode == 0) ? d->path_hint : 2;
     if (tail && (!ka.u_opt_smooth || d->phase != 0)) { set_err(err, "the sweep's scoring tail needs a full call (phase 0) with fp64 u_opt_smooth selected"); return EPI_ERR_BAD_ARG; }
@@ -1724,6 +1813,7 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     epi_batch_desc d = *d0;
     const size_t Bfull = (size_t)d0->B;
     d.B = n;
+    d.exact_nonfinite = 1;     // a host call returns what the dense evaluation returns, overflowed chains included
     const bool id_x = !in->x_series, id_u = !in->u_series;      // identity series: one series per chain, sliced with the chains
     if (id_x) d.Sx = n;
     if (id_u) d.Su = n;
@@ -1948,6 +2038,7 @@ static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_
     d.n_npi = pd->n_npi; d.L = pd->L; d.order = pd->order; d.obs_type = pd->obs_type; d.r_mode = 1; d.q_mode = 0;
     d.out_mask = pd->out_mask | EPI_OUT_U_OPT_SMOOTH | (out->S_opt ? EPI_OUT_S_SMOOTH : 0u);
     d.shape = pd->shape; d.time_pipe = pd->time_pipe;
+    d.exact_nonfinite = 1;
     {
         epi_inputs hin{};
         hin.s_init = in->s_init; hin.Ps_init = in->Ps_init; hin.s_final = in->s_final; hin.Ps_final = in->Ps_final; hin.Q = in->Q;
@@ -2103,7 +2194,7 @@ static int sialpha_launch(const epi_sim_desc *d, const int32_t *u_series, const 
     }
     const int blocks = (d->B + 255) / 256;
     hipLaunchKernelGGL(sialpha_sim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d, u_series, u, sp, z, s, i, alpha,
-                       J0, J1, J0_prefix, J1_prefix);
+                       J0, J1, J0_prefix, J1_prefix, (const int32_t *)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(err, e, "sialpha_sim launch");
     return EPI_OK;
@@ -2151,7 +2242,7 @@ int epi_pareto_front_device(int32_t R, int32_t P, const double *J0, const double
         hipError_t e = hipFuncSetAttribute((const void *)pareto_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return hip_fail(err, e, "hipFuncSetAttribute");
     }
-    hipLaunchKernelGGL(pareto_front, dim3(R), dim3(256), shmem, (hipStream_t)stream, P, J0, J1, on_front, i_opt);
+    hipLaunchKernelGGL(pareto_front, dim3(R), dim3(256), shmem, (hipStream_t)stream, P, J0, J1, on_front, i_opt, (const int32_t *)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(err, e, "pareto_front launch");
     return EPI_OK;

@@ -96,8 +96,10 @@ EPI_DEV bool argmin_better(double v, int i, double bv, int bi)
 
 // J0, J1: [R][P] (the sweep's chain order: region-major, cost weight fastest).  on_front [R][P]; i_opt [R] (0-based).
 __global__ __launch_bounds__(256) void pareto_front(int P, const double *__restrict__ J0, const double *__restrict__ J1,
-                                                    int32_t *__restrict__ on_front, int32_t *__restrict__ i_opt)
+                                                    int32_t *__restrict__ on_front, int32_t *__restrict__ i_opt,
+                                                    const int32_t *__restrict__ gate)
 {
+    if (gate && *gate == 0) return;   // second pass after the dense re-run of non-finite chains: nothing was re-run
     extern __shared__ double pts[];   // [2][P]
     __shared__ double red_a[256], red_b[256];
     __shared__ int red_i[256];

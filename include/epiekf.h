@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define EPIEKF_ABI_VERSION 3
+#define EPIEKF_ABI_VERSION 4
 
 /* which reference function the chain runs */
 typedef enum epi_model {
@@ -147,15 +147,27 @@ typedef struct epi_batch_desc {
                              1 = one lane per chain (ekf_fwd_sym / eks_bwd_sym: least total work, what a batch that fills
                              the chip wants), 2 = four lanes per chain (ekf_fwd_quad / eks_bwd_quad: every 6 x 6 matrix as
                              a 2 x 2 grid of 3 x 3 blocks over a DPP quad; a ~2x shorter per-day instruction stream and
-                             4x the wavefronts, what a batch that does NOT fill the chip wants -- DESIGN.md 4).
-                             Results are bit-identical in both shapes.  Ignored by the other models. */
+                             4x the wavefronts, what a batch that does NOT fill the chip wants -- DESIGN.md 4),
+                             3 = one WAVEFRONT per chain (ekf_fwd_wave / eks_bwd_wave: lane e = i + 6 j owns element (i, j) of
+                             every 6 x 6 matrix, operands exchanged through LDS; the shortest per-day latency, for batches of
+                             at most one chain per SIMD -- the reference's own one-call-per-cost-weight loop; needs R_v as a
+                             per-day series, else falls back to 2).  Auto: 3 up to 1024 chains, 2 up to 16 384, then 1.
+                             Results are bit-identical in all shapes.  Ignored by the other models. */
     int32_t storage;      /* element type of the OUTPUT arrays: 0 = fp64 (the reference's), 1 = fp32 storage with fp64
                              register arithmetic (BASELINE config 5): every selected output is the fp64 result rounded
                              once to fp32; the forward quantities the smoother reads back stay fp64 in the workspace.
                              epi_ekf_run_device only. */
+    int32_t exact_nonfinite; /* 1: chains whose covariance overflows (status bit 0: the non-finite guard of GenericEKF.m:211
+                             fired) are run a second time by the dense kernels, in place, so that their Inf / NaN pattern is
+                             the dense evaluation's -- the reference's, and the C oracle's -- at every day.  The packed and
+                             quad kernels skip products with structural zeros, which is exact only for finite operands: after
+                             an overflow they may carry a finite number where MATLAB has NaN.  Generic models, full call
+                             (phase 0), fixed Q_w, fp64 storage; costs three launches that return at once when no chain is
+                             marked (~0.15 ms at 75 000 x 520) and needs (B + 1 + B) more int32 of workspace.  The *_host
+                             entry points always set it.  0: as the kernels leave them (`status` still tells which chains). */
 } epi_batch_desc;
 
-typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2 } epi_shape;
+typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3 } epi_shape;
 
 typedef struct epi_inputs {
     const int32_t *x_series; /* [B] or NULL */

@@ -29,9 +29,12 @@ for _ in range(2):
                                                     C.c_void_p(st.cuda_stream), err), err)
 torch.cuda.synchronize()
 del src, dst
-# `python traffic_probe.py shard`: the 9 375-chain shard one of 8 GPUs runs (four lanes per chain) instead of the whole sweep
-w = synth.make_cfg4(75, 125) if (len(sys.argv) > 1 and sys.argv[1] == "shard") else synth.make_cfg4()
-r = batch.EkfRunner(batch.DeviceWorkload(w, dev), lane_block="auto")   # bench.py's default layout and lane mapping
+# `python traffic_probe.py shard`: the 9 375-chain shard one of 8 GPUs runs (four lanes per chain) instead of the whole sweep;
+# `live`: the living multi-wave epidemic (bench.py --workload cfg4-live); `reduced`: the two outputs the caller consumes
+args = set(sys.argv[1:])
+w = synth.make_cfg4(75, 125, live="live" in args) if "shard" in args else synth.make_cfg4(live="live" in args)
+outs = ["u_opt_smooth", "S_SMOOTH"] if "reduced" in args else None
+r = batch.EkfRunner(batch.DeviceWorkload(w, dev), outputs=outs, lane_block="auto")   # bench.py's default layout and lane mapping
 for _ in range(2):
     for ph in (1, 3, 4):
         r.run(phase=ph)

@@ -77,6 +77,15 @@ def batch_chain(out, name, c, m):
     return v.T
 
 
+def oracle_guard_fired(ref, model):
+    """[B] bool from an oracle result: did the non-finite guard of GenericEKF.m:211 fire at any executed smoother step
+    (pinv_rank == -1 there)?  That is bit 0 of the library's per-chain `status`.  The smoother never executes the last
+    column (the first one for the time-flipped wrappers), whose rank word is -1 by convention."""
+    rk = ref["pinv_rank"]
+    ex = rk[1:] if "Backward" in model else rk[:-1]
+    return (ex == -1).any(axis=0)
+
+
 def rel_err(a, b):
     """max |a-b| / max(|b|) over finite entries, with NaN/Inf patterns required to match."""
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
