@@ -18,8 +18,11 @@
 //     in 6 different arrangements); every element's fma chain runs k-ascending in ONE lane, dense (no structural zero
 //     is skipped), which is the C oracle's and the dense kernels' rounding sequence term for term: results are bit for
 //     bit the other shapes', non-finite values included;
-//   * the step's inputs and, in the smoother, the stored forward quantities are requested one step ahead; every array
-//     slice is addressed through a buffer descriptor with one per-lane byte offset per array kind.
+//   * broadcasts of a single lane's value (C P, the gain, J d) go through v_readlane, transposed elements through
+//     ds_bpermute -- no LDS write, no wait for it; the Jacobian's 21 non-zero entries are each evaluated by the lane that
+//     owns them (w_jac_entry) instead of 45 wave-uniform multiplications;
+//   * the step's inputs and, in the smoother, the stored forward quantities are requested one step ahead; every lane walks
+//     its own element of each array with a 64-bit pointer in VGPRs.
 #pragma once
 // (included inside namespace epi, like ekf_sym.hpp / ekf_quad.hpp)
 
@@ -28,11 +31,7 @@ constexpr int kWE = 36;     // lanes that own a matrix element
 struct WaveLane {
     int e, i, j;            // element, row, column (lanes >= 36 mirror element 0: their results are never stored)
     int k;                  // NPI owned (lanes >= 12 mirror NPI 0: never stored)
-    bool own, npi;
-    unsigned v36, v6, vn, v21;   // byte offsets of this lane's row in a 36- / 6- / n_npi- / 21-row time slice (loads)
-    unsigned v1i;                  // one-row int32 arrays (loads)
-    unsigned s36, s6, sn, s1, s1i; // the same for stores: out of range for lanes that own nothing of the array
-    unsigned rowb;
+    bool own, npi, first;   // owns a matrix element / an NPI of this batch (k < n_npi) / is lane 0
 };
 
 EPI_DEV void w_row(const double *buf, int r, double (&o)[6])
@@ -52,36 +51,7 @@ EPI_DEV double w_dot6(const double (&x)[6], const double (&y)[6])     // x[0]*y[
     for (int q = 1; q < 6; q++) acc = fma(x[q], y[q], acc);
     return acc;
 }
-EPI_DEV rsrc_t w_slice(const void *p, int t, unsigned rows, const Lay &l, unsigned elem = 8u)
-{
-    return mk_rsrc((const char *)p + (size_t)t * rows * l.bp * elem, rows * l.bp * elem);
-}
-// The time slices of the arrays a kernel walks, as RUNNING byte offsets (one 64-bit add per kind and step instead of a
-// 64-bit multiply per array and step): slice t of an array with `rows` rows starts at t * rows * bp * elem.
-struct WaveWalk {
-    long o36, o21, o6, on, o1, o1i, ou;      // offsets of the current slice for 36- / 21- / 6- / n_npi-row fp64 arrays, one-row fp64 / int32 arrays, the control series
-    long d36, d21, d6, dn, d1, d1i, du;      // what one step adds (negative when the walk runs down the caller's time axis)
-    unsigned z36, z21, z6, zn, z1, z1i, zu;  // slice sizes in bytes
-};
-EPI_DEV WaveWalk w_walk(const KArgs &a, const Lay &l, int t0, int dir)
-{
-    WaveWalk k;
-    const long bp = (long)l.bp;
-    k.z36 = (unsigned)(36 * bp * 8); k.z21 = (unsigned)(21 * bp * 8); k.z6 = (unsigned)(6 * bp * 8);
-    k.zn = (unsigned)((long)a.n_npi * bp * 8); k.z1 = (unsigned)(bp * 8); k.z1i = (unsigned)(bp * 4);
-    k.zu = (unsigned)((long)a.n_npi * a.Su * 8);
-    k.o36 = (long)t0 * k.z36; k.o21 = (long)t0 * k.z21; k.o6 = (long)t0 * k.z6; k.on = (long)t0 * k.zn;
-    k.o1 = (long)t0 * k.z1; k.o1i = (long)t0 * k.z1i; k.ou = (long)t0 * k.zu;
-    k.d36 = dir * (long)k.z36; k.d21 = dir * (long)k.z21; k.d6 = dir * (long)k.z6; k.dn = dir * (long)k.zn;
-    k.d1 = dir * (long)k.z1; k.d1i = dir * (long)k.z1i; k.du = dir * (long)k.zu;
-    return k;
-}
-EPI_DEV void w_advance(WaveWalk &k)
-{
-    k.o36 += k.d36; k.o21 += k.d21; k.o6 += k.d6; k.on += k.dn; k.o1 += k.d1; k.o1i += k.d1i; k.ou += k.du;
-}
-EPI_DEV rsrc_t w_at(const void *p, long off, unsigned size) { return mk_rsrc((const char *)p + off, size); }
-EPI_DEV WaveLane w_lane(const KArgs &a, const Lay &lay)
+EPI_DEV WaveLane w_lane(const KArgs &a)
 {
     WaveLane w;
     w.own = threadIdx.x < kWE;
@@ -89,50 +59,119 @@ EPI_DEV WaveLane w_lane(const KArgs &a, const Lay &lay)
     w.j = w.e / 6; w.i = w.e - 6 * w.j;
     w.npi = (int)threadIdx.x < a.n_npi;
     w.k = threadIdx.x < kNpi ? (int)threadIdx.x : 0;
-    w.rowb = lay.blk * 8u;
-    // STORES are unconditional: a lane that owns nothing of an array carries an offset beyond the slice, and the buffer
-    // descriptor's bounds check drops its store (no EXEC toggling around the ~10 stores of a step)
-    constexpr unsigned OOB = 0x80000000u;     // slices stay below 2 GiB (B <= 2^20 in this shape), offset + row offset below 4 GiB
-    w.v36 = (lay.cb * 36u * lay.blk + lay.cr) * 8u + (unsigned)w.e * w.rowb;
-    w.s36 = w.own ? w.v36 : OOB;
-    w.v6 = (lay.cb * 6u * lay.blk + lay.cr) * 8u;                                     // + row * rowb as the scalar offset
-    w.s6 = threadIdx.x == 0 ? w.v6 : OOB;
-    w.s1 = threadIdx.x == 0 ? lay.c * 8u : OOB;                                       // one-row arrays [T][nblk*blk]
-    w.s1i = threadIdx.x == 0 ? lay.c * 4u : OOB;
-    w.v1i = lay.c * 4u;
-    w.vn = (lay.cb * (unsigned)a.n_npi * lay.blk + lay.cr) * 8u + (unsigned)w.k * w.rowb;
-    w.sn = w.npi ? w.vn : OOB;
-    const int lo = w.i < w.j ? w.i : w.j, hi = w.i < w.j ? w.j : w.i;
-    w.v21 = (lay.cb * 21u * lay.blk + lay.cr) * 8u + (unsigned)(lo + hi * (hi + 1) / 2) * w.rowb;
+    w.first = threadIdx.x == 0;
     return w;
 }
-// a wave-uniform 6-vector: six stores with scalar row offsets, kept by lane 0 only (the others are out of range)
-EPI_DEV void w_store_vec(double *dst, long off, unsigned size, const WaveLane &w, const double (&v)[6])
+// Addressing: every lane walks its OWN element of each array with a 64-bit pointer held in VGPRs (one add per array and
+// step); element (t, row, c) of an array with `rows` rows sits at ((t * nblk + cb) * rows + row) * blk + cr doubles, and one
+// time step moves by rows * bp doubles (down the caller's time axis for the time-flipped wrappers).  No buffer descriptors:
+// fourteen of them would not fit the scalar registers beside the lane masks of the Jacobian's entry kinds.
+EPI_DEV size_t w_elem(const Lay &l, int t, unsigned rows, unsigned row)
 {
-    if (!dst) return;
-    const rsrc_t r = w_at(dst, off, size);
-#pragma unroll
-    for (int q = 0; q < 6; q++) bst(r, w.s6, (unsigned)q * w.rowb, v[q]);
+    return ((size_t)t * l.nblk + l.cb) * rows * l.blk + (size_t)row * l.blk + l.cr;
 }
-EPI_DEV void w_load_vec(const double *src, long off, unsigned size, const WaveLane &w, double (&v)[6])
+// a wave-uniform 6-vector at `p` (the position of row 0; rows `blk` doubles apart): written by the calling lane
+EPI_DEV void w_put_vec(double *p, unsigned blk, const double (&v)[6])
 {
-    const rsrc_t r = w_at(src, off, size);
 #pragma unroll
-    for (int q = 0; q < 6; q++) v[q] = bld(r, w.v6, (unsigned)q * w.rowb);
+    for (int q = 0; q < 6; q++) p[(size_t)q * blk] = v[q];
+}
+EPI_DEV void w_get_vec(const double *p, unsigned blk, double (&v)[6])
+{
+#pragma unroll
+    for (int q = 0; q < 6; q++) v[q] = p[(size_t)q * blk];
+}
+// keeps a wave-uniform value in a VGPR (the compiler would otherwise hold the ~25 model constants of a chain in scalar
+// registers, and spill the lane masks that select the Jacobian's entry kinds)
+EPI_DEV double w_vgpr(double v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
 }
 
-// the uniform Jacobian written to LDS for per-lane row reads.  All lanes hold the same values; structurally zero entries
-// were zeroed once at kernel start and are never written again (jacobian_entries: the zero pattern is fixed per model).
-EPI_DEV void w_put_jacobian(double *sA, const double (&A)[36])
+// ---- cross-lane moves without an LDS write ---------------------------------------------------------------------------
+// a value held by lane `src` (compile-time lane) to every lane, through two v_readlane_b32
+EPI_DEV double w_bcast(double v, int src)
 {
-    constexpr int M = 6;
-    sA[IXM(0, 0)] = A[IXM(0, 0)]; sA[IXM(0, 1)] = A[IXM(0, 1)]; sA[IXM(0, 2)] = A[IXM(0, 2)];
-    sA[IXM(1, 0)] = A[IXM(1, 0)]; sA[IXM(1, 1)] = A[IXM(1, 1)]; sA[IXM(1, 2)] = A[IXM(1, 2)];
-    sA[IXM(2, 2)] = A[IXM(2, 2)]; sA[IXM(2, 5)] = A[IXM(2, 5)];
-    sA[IXM(3, 1)] = A[IXM(3, 1)]; sA[IXM(3, 2)] = A[IXM(3, 2)]; sA[IXM(3, 3)] = A[IXM(3, 3)]; sA[IXM(3, 4)] = A[IXM(3, 4)];
-    sA[IXM(4, 0)] = A[IXM(4, 0)]; sA[IXM(4, 2)] = A[IXM(4, 2)]; sA[IXM(4, 3)] = A[IXM(4, 3)]; sA[IXM(4, 4)] = A[IXM(4, 4)];
-    sA[IXM(5, 0)] = A[IXM(5, 0)]; sA[IXM(5, 1)] = A[IXM(5, 1)]; sA[IXM(5, 3)] = A[IXM(5, 3)]; sA[IXM(5, 4)] = A[IXM(5, 4)];
-    sA[IXM(5, 5)] = A[IXM(5, 5)];
+    const u32x2 b = __builtin_bit_cast(u32x2, v);
+    u32x2 r;
+    r.x = (unsigned)__builtin_amdgcn_readlane((int)b.x, src);
+    r.y = (unsigned)__builtin_amdgcn_readlane((int)b.y, src);
+    return __builtin_bit_cast(double, r);
+}
+// the value of lane `srcb / 4` (per-lane choice), through two ds_bpermute_b32 (the LDS crossbar, no LDS memory)
+EPI_DEV double w_from(double v, int srcb)
+{
+    const u32x2 b = __builtin_bit_cast(u32x2, v);
+    u32x2 r;
+    r.x = (unsigned)__builtin_amdgcn_ds_bpermute(srcb, (int)b.x);
+    r.y = (unsigned)__builtin_amdgcn_ds_bpermute(srcb, (int)b.y);
+    return __builtin_bit_cast(double, r);
+}
+
+// ---- the Jacobian, every entry by the lane that owns it --------------------------------------------------------------
+// StateJacobians (OptControlled.m:89-135, Backward...m:109-156) has four kinds of entries; each lane evaluates its own with
+// the operation order of jacobian_entries() (ekf_device.hpp), which the dense kernels and the C oracle share:
+//   S1     base + sgn ((dt * X) * Y)      X in {s1, s2, s3}, Y in {s1, s2, s3, rho}, base 0 or 1
+//   S2     1 + sgn (dt * (s1 * s3 - beta))                                        (entries (2,2) and (5,5), 1-based)
+//   CONST  1 -/+ dt * gamma ((3,3), (6,6)), or a structural zero
+//   A36    the slope term of the bang-bang control ((3,6)): left 0.0 here, patched in by the lanes that read row 3
+// `-(x)` and `1.0 + (-x)` are the bits of `-dt * ...` and `1.0 - ...` as written there.
+struct WaveJac {
+    bool x0, x1, y0, y1, y2, s2, neg, base1, cst;   // X = x0 ? s1 : (x1 ? s2 : s3);  Y = y0 ? s1 : (y1 ? s2 : (y2 ? s3 : rho))
+    double c;                                       // CONST value
+};
+template <int FLIP>
+EPI_DEV WaveJac w_jac_setup(const QPrm &p, const WaveLane &w)
+{
+    // per entry e = i + 6 j: kind (0 zero, 1 S1, 2 S2, 3 CONST, 4 A36), X, Y (3 = rho), sign (1 = minus), base
+    struct E { unsigned char kind, x, y, neg, base1; };
+    const E Z{0, 0, 0, 0, 0};
+    E tab[36];
+#pragma unroll
+    for (int q = 0; q < 36; q++) tab[q] = Z;
+    auto set = [&](int i, int j, E v) { tab[i + 6 * j] = v; };
+    set(0, 0, E{1, 2, 1, 1, 1}); set(0, 1, E{1, 2, 0, 1, 0}); set(0, 2, E{1, 0, 1, 1, 0});
+    set(1, 0, E{1, 1, 2, 0, 0}); set(1, 1, E{2, 0, 0, 0, 1}); set(1, 2, E{1, 0, 1, 0, 0});
+    set(2, 2, E{3, 0, 0, 1, 1}); set(2, 5, E{4, 0, 0, 0, 0});
+    set(3, 1, E{1, 2, 3, 0, 0}); set(3, 2, E{1, 1, 3, 0, 0}); set(3, 3, E{1, 1, 2, 0, 1}); set(3, 4, E{1, 1, 2, 1, 0});
+    set(4, 0, E{1, 2, 3, 0, 0}); set(4, 2, E{1, 0, 3, 0, 0}); set(4, 3, E{1, 0, 2, 0, 0}); set(4, 4, E{2, 0, 0, 1, 1});
+    set(5, 0, E{1, 1, 3, 0, 0}); set(5, 1, E{1, 0, 3, 0, 0}); set(5, 3, E{1, 0, 1, 0, 0}); set(5, 4, E{1, 0, 1, 1, 0});
+    set(5, 5, E{3, 0, 0, 0, 1});
+    E me = Z;
+#pragma unroll
+    for (int q = 0; q < 36; q++)
+        if (w.e == q) me = tab[q];
+    WaveJac j;
+    j.x0 = me.x == 0; j.x1 = me.x == 1;
+    j.y0 = me.y == 0; j.y1 = me.y == 1; j.y2 = me.y == 2;
+    j.s2 = me.kind == 2;
+    j.neg = (me.neg != 0) != (FLIP != 0);          // the time-flipped model reverses the sign of every dt term
+    j.base1 = me.base1 != 0;
+    j.cst = me.kind == 0 || me.kind == 3 || me.kind == 4;
+    const double dg = p.dt * p.gamma;
+    j.c = me.kind == 3 ? (j.neg ? 1.0 - dg : 1.0 + dg) : 0.0;
+    return j;
+}
+EPI_DEV double w_jac_entry(const QPrm &p, const WaveJac &j, const double (&s)[6])
+{
+    const double rho = s[3] - s[4] - (1.0 - p.epsilon);
+    const double w2 = p.dt * (s[0] * s[2] - p.beta);
+    const double X = j.x0 ? s[0] : (j.x1 ? s[1] : s[2]);
+    const double Y = j.y0 ? s[0] : (j.y1 ? s[1] : (j.y2 ? s[2] : rho));
+    double v = p.dt * X * Y;
+    v = j.s2 ? w2 : v;
+    v = j.neg ? -v : v;
+    const double r = j.base1 ? 1.0 + v : v;
+    return j.cst ? j.c : r;
+}
+// rows i and j of the Jacobian as the owners left them in LDS, with the slope term patched into entry (3,6)
+EPI_DEV void w_jac_rows(const double *sA, const WaveLane &w, double a36, double (&ri)[6], double (&rj)[6])
+{
+    w_row(sA, w.i, ri);
+    w_row(sA, w.j, rj);
+    ri[5] = (w.i == 2) ? a36 : ri[5];
+    rj[5] = (w.j == 2) ? a36 : rj[5];
 }
 
 // ---- the NPI lanes ------------------------------------------------------------------------------------------------
@@ -149,6 +188,9 @@ EPI_DEV void w_load_prm(QPrm &p, WaveNpi &n, const KArgs &a, int B, int c, const
     p.slo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_S_MIN);
     p.ilo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_I_MIN);
     p.alpha_min = g(EPI_PRM_ALPHA_MIN); p.alpha_max = g(EPI_PRM_ALPHA_MAX);
+    p.dt = w_vgpr(p.dt); p.beta = w_vgpr(p.beta); p.gamma = w_vgpr(p.gamma); p.sigma = w_vgpr(p.sigma); p.b = w_vgpr(p.b);
+    p.epsilon = w_vgpr(p.epsilon); p.slo = w_vgpr(p.slo); p.ilo = w_vgpr(p.ilo);
+    p.alpha_min = w_vgpr(p.alpha_min); p.alpha_max = w_vgpr(p.alpha_max);
     n.inv_sigma = 1.0 / p.sigma;
     n.a = g(EPI_PRM_A + w.k); n.umin = g(EPI_PRM_U_MIN + w.k); n.umax = g(EPI_PRM_U_MAX + w.k);
     n.ew = p.epsilon * g(EPI_PRM_W_EFF + w.k);
@@ -156,12 +198,8 @@ EPI_DEV void w_load_prm(QPrm &p, WaveNpi &n, const KArgs &a, int B, int c, const
     n.term = p.gamma * p.dt * (p.sigma / 2.0) * n.a * (n.umax - n.umin);
     if (threadIdx.x < kNpi) sGa[w.k] = p.gamma * n.a;
 }
-// u(k, t) of my NPI (rows beyond n_npi read 0.0 through the descriptor's bounds check, see load_u); `off` = byte offset
-// of time slice t of the control series, `vu` = this lane's offset in it
-EPI_DEV double w_load_u(const KArgs &a, long off, unsigned size, unsigned vu)
-{
-    return bld(w_at(a.u, off, size), vu, 0u);
-}
+// u(k, t) of my NPI: rows beyond n_npi read as 0.0, the padding value of load_u()
+EPI_DEV double w_load_u(const double *pu, const WaveLane &w) { return w.npi ? *pu : 0.0; }
 // my NPI at state s: phi (OptControlled.m:49), the control applied (:50-58, strict >) and my slope-term contribution
 // (:107-114; 0.0 where the dense code adds nothing -- x - 0.0 == x, so the running sum keeps its bits)
 EPI_DEV void w_npi(const QPrm &p, const WaveNpi &n, double u, double s6, double &uapp, double &tterm)
@@ -197,7 +235,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
 {
     constexpr int M = 6;
     // tiles are 64 entries so that every lane writes its slot unconditionally (lanes >= 36 own padding)
-    __shared__ double sP[kWave], sT[kWave], sA[kWE], sV[16], sGa[kNpi], sD[kWave], sTt[kWave];
+    __shared__ double sP[kWave], sT[kWave], sA[kWave], sGa[kNpi], sD[kWave], sTt[kWave];
     if (*dense_flag) return;
     const int c = a.c0 + (int)blockIdx.x;
     if (c >= a.c0 + a.cn) return;
@@ -205,47 +243,56 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
     const int sx = a.x_series ? a.x_series[c] : c;
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
-    const WaveLane w = w_lane(a, lay);
+    const WaveLane w = w_lane(a);
     const unsigned lane = threadIdx.x;
+    const int tr_b = (w.j + 6 * w.i) * 4;               // ds_bpermute address of the lane that owns the transposed element
 
     QPrm p;
     WaveNpi np;
     w_load_prm(p, np, a, B, c, w, sGa);
-    const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
-    const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
+    const WaveJac jc = w_jac_setup<FLIP>(p, w);
+    const double v_bar = w_vgpr(a.prm[(size_t)EPI_PRM_V_BAR * B + c]);
+    const double gamma = w_vgpr(a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c]);
 
     double sk_minus[M];
 #pragma unroll
     for (int i = 0; i < M; i++) sk_minus[i] = a.s_init[(size_t)i * B + c];
     double Pm = a.Ps_init[(size_t)w.e * B + c];
     const double Qe = a.Q[(size_t)w.e * B + c];
-    if (w.own) sA[w.e] = 0.0;
 
     const int k_begin = a.k_begin, k_end = (a.k_end > 0 && a.k_end < T) ? a.k_end : T;
-    WaveWalk wk = w_walk(a, lay, tpos<FLIP>(k_begin, T), FLIP ? -1 : 1);
+    const int t0 = tpos<FLIP>(k_begin, T);
+    const long dir = FLIP ? -1L : 1L;
+    const long bp = (long)lay.bp;
+    const unsigned blk = lay.blk;
+    // this lane's element of time slice t0 of every array the kernel writes, and the per-step strides
+    double *pSm = a.S_MINUS + w_elem(lay, t0, 6u, 0u), *pSp = a.S_PLUS + w_elem(lay, t0, 6u, 0u);
+    double *pKg = a.K_GAIN ? a.K_GAIN + w_elem(lay, t0, 6u, 0u) : nullptr;
+    double *pPm = a.P_MINUS + w_elem(lay, t0, 36u, (unsigned)w.e), *pPp = a.P_PLUS + w_elem(lay, t0, 36u, (unsigned)w.e);
+    double *pUo = a.u_opt ? a.u_opt + w_elem(lay, t0, (unsigned)a.n_npi, (unsigned)w.k) : nullptr;
+    double *pIn = a.innovations ? a.innovations + lay_scalar(t0, lay) : nullptr;
+    const long d6 = dir * 6 * bp, d36 = dir * 36 * bp, dn = dir * (long)a.n_npi * bp, d1 = dir * bp;
+    const double *pu = a.u + ((size_t)t0 * a.n_npi + (size_t)w.k) * a.Su + su;
+    const long du = dir * (long)a.n_npi * a.Su;
+    const long dx = dir * a.Sx;                           // x walks the caller's time axis, R_v the filter's (Backward*.m:27)
+    const double *px = a.x + (size_t)t0 * a.Sx + sx, *pr = a.R_series + (size_t)k_begin * a.Sx + sx;
     if (k_begin > 0) {           // a later time segment resumes from what the previous one stored
-        w_load_vec(a.S_MINUS, wk.o6, wk.z6, w, sk_minus);
-        Pm = bld(w_at(a.P_MINUS, wk.o36, wk.z36), w.v36, 0u);
+        w_get_vec(pSm, blk, sk_minus);
+        Pm = *pPm;
+    } else {                     // :100-101 for the first step (later steps: stored at the end of the step before)
+        if (w.first) w_put_vec(pSm, blk, sk_minus);
+        if (w.own) *pPm = Pm;
     }
-    const unsigned vu = (unsigned)su * 8u + (unsigned)w.k * (unsigned)a.Su * 8u;
-    const long dx = (FLIP ? -1L : 1L) * a.Sx;             // x walks the caller's time axis, R_v the filter's (Backward*.m:27)
-    const double *px = a.x + (size_t)tpos<FLIP>(k_begin, T) * a.Sx + sx, *pr = a.R_series + (size_t)k_begin * a.Sx + sx;
     double x_nxt = *px, r_nxt = *pr;
-    double u_nxt = w_load_u(a, wk.ou, wk.zu, vu);
+    double u_nxt = w_load_u(pu, w);
 
     for (int k = k_begin; k < k_end; k++) {
         const double Rk = r_nxt, xk = x_nxt, u_in = u_nxt;
         if (k + 1 < T) {
-            px += dx; pr += a.Sx;
+            px += dx; pr += a.Sx; pu += du;
             x_nxt = *px; r_nxt = *pr;
-            u_nxt = w_load_u(a, wk.ou + wk.du, wk.zu, vu);
+            u_nxt = w_load_u(pu, w);
         }
-
-        // :100-101
-        w_store_vec(a.S_MINUS, wk.o6, wk.z6, w, sk_minus);
-        bst(w_at(a.P_MINUS, wk.o36, wk.z36), w.s36, 0u, Pm);
-        sP[lane] = Pm;
-        __syncthreads();
 
         double C[M];
         obs_jacobian<M>(a.mf, sk_minus, C);                              // :115
@@ -253,6 +300,8 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
         double innov, K[M], sk_plus[M], Pp;
         const bool valid = !is_nan(xk);                                  // :122 (wave-uniform)
         if (valid) {
+            sP[lane] = Pm;
+            __syncthreads();
             innov = xk - xk_minus;
             double prow[6], pcol[6];
             w_row(sP, w.i, prow);
@@ -261,18 +310,12 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
             double CP_j = C[0] * pcol[0];                                // (C P)(j): C(0)*P(0,j), fma ...
 #pragma unroll
             for (int q = 1; q < M; q++) CP_j = fma(C[q], pcol[q], CP_j);
-            if (w.i == 0) sV[w.j] = CP_j;                                // (mirror lanes rewrite entry 0 with lane 0's value)
-            __syncthreads();
-            double CP[M];
+            double CPCt = w_bcast(CP_j, 0) * C[0];                       // lane 6 q holds (C P)(q)
 #pragma unroll
-            for (int q = 0; q < M; q++) CP[q] = sV[q];
-            double CPCt = CP[0] * C[0];
-#pragma unroll
-            for (int q = 1; q < M; q++) CPCt = fma(CP[q], C[q], CPCt);
+            for (int q = 1; q < M; q++) CPCt = fma(w_bcast(CP_j, 6 * q), C[q], CPCt);
             const double den = CPCt + gamma * Rk;                        // :124 (D = 1, Hessian terms 0)
             // P(k|k-1) is bit-wise symmetric (symmetrised at :161; Ps_init by ekf_precheck), so (C P)(j) == (P C')(j)
             const double K_i = PCt_i / den, K_j = CP_j / den;
-            if (w.j == 0) sV[8 + w.i] = K_i;
             double ikc_i[6], ikc_j[6];
 #pragma unroll
             for (int q = 0; q < M; q++) {
@@ -282,14 +325,14 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
             const double T1 = w_dot6(ikc_i, pcol);                       // ((I - K C) P)(i,j)
             sT[lane] = T1;
             __syncthreads();
+#pragma unroll
+            for (int q = 0; q < M; q++) K[q] = w_bcast(K_i, q);          // lane q holds K(q)
+#pragma unroll
+            for (int q = 0; q < M; q++) sk_plus[q] = sk_minus[q] + K[q] * innov;   // :129
             double t1row[6];
             w_row(sT, w.i, t1row);
             const double T2 = w_dot6(t1row, ikc_j);                      // Joseph form :127
             Pp = (T2 + (K_i * Rk) * K_j) / gamma;
-#pragma unroll
-            for (int q = 0; q < M; q++) K[q] = sV[8 + q];
-#pragma unroll
-            for (int q = 0; q < M; q++) sk_plus[q] = sk_minus[q] + K[q] * innov;   // :129
         } else {                                                         // :130-135
             innov = 0.0;
 #pragma unroll
@@ -297,63 +340,58 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
             Pp = Pm;
         }
         state_hard_margins<M>(p, sk_plus);                               // :141
-        // my NPI at s(k|k): the control applied and the slope-term contribution  :155-157
+        // my NPI at s(k|k): the control applied and the slope-term contribution; my entry of the Jacobian  :155-157
         double u_app, tterm;
         w_npi(p, np, u_in, sk_plus[5], u_app, tterm);
-        // :138  (P + P')/2.0
+        const double myA = w_jac_entry(p, jc, sk_plus);
+        Pp = (Pp + w_from(Pp, tr_b)) / 2.0;                              // :138  (P + P')/2.0
         __syncthreads();
-        sP[lane] = Pp;
+        sP[lane] = Pp;                                                   // the symmetrised P(k|k)
+        sA[lane] = myA;
         sD[lane] = np.umax - u_app;
         sTt[lane] = tterm;
         __syncthreads();
-        Pp = (Pp + sP[w.j + 6 * w.i]) / 2.0;
 
         // s(k+1|k), P(k+1|k)  :155-164
         double sk_next[M];
         {
-            const double dot = w_dot_npi(sGa, sD);
             const double a36 = w_slope<FLIP>(sTt);
-            state_map<M, FLIP>(p, dot, sk_plus, sk_next);
-            double A[M * M];
-            jacobian_entries<M, FLIP>(p, sk_plus, a36, A);
-            __syncthreads();
-            w_put_jacobian(sA, A);
-            sT[lane] = Pp;                                               // the symmetrised P(k|k)
-            __syncthreads();
             double arow_i[6], arow_j[6], ppcol[6];
-            w_row(sA, w.i, arow_i);
-            w_row(sA, w.j, arow_j);
-            w_col(sT, w.j, ppcol);
+            w_jac_rows(sA, w, a36, arow_i, arow_j);
+            w_col(sP, w.j, ppcol);
             const double T1 = w_dot6(arow_i, ppcol);                     // (A P+)(i,j)
-            __syncthreads();
-            sP[lane] = T1;
+            sT[lane] = T1;
+            const double dot = w_dot_npi(sGa, sD);
+            state_map<M, FLIP>(p, dot, sk_plus, sk_next);
             __syncthreads();
             double t1row[6];
-            w_row(sP, w.i, t1row);
+            w_row(sT, w.i, t1row);
             const double T2 = w_dot6(t1row, arow_j);                     // (A P+ A')(i,j)
             double Pn = T2 + Qe;                                         // B = I
-            __syncthreads();
-            sT[lane] = Pn;
-            __syncthreads();
-            Pn = (Pn + sT[w.j + 6 * w.i]) / 2.0;                         // :161
+            Pn = (Pn + w_from(Pn, tr_b)) / 2.0;                          // :161
             Pm = Pn;
         }
         state_hard_margins<M>(p, sk_next);                               // :164
 
-        // :167-169
-        w_store_vec(a.S_PLUS, wk.o6, wk.z6, w, sk_plus);
-        w_store_vec(a.K_GAIN, wk.o6, wk.z6, w, K);
-        if (a.innovations) bst(w_at(a.innovations, wk.o1, wk.z1), w.s1, 0u, innov);
-        if (a.u_opt) bst(w_at(a.u_opt, wk.on, wk.zn), w.sn, 0u, u_app);
-        bst(w_at(a.P_PLUS, wk.o36, wk.z36), w.s36, 0u, Pp);
+        // :167-169, and :100-101 of the next step (also the hand-over to a later time segment)
+        const bool more = k + 1 < T;
+        if (w.first) {
+            w_put_vec(pSp, blk, sk_plus);
+            if (pKg) w_put_vec(pKg, blk, K);
+            if (pIn) *pIn = innov;
+            if (more) w_put_vec(pSm + d6, blk, sk_next);
+        }
+        if (w.own) {
+            *pPp = Pp;
+            if (more) pPm[d36] = Pm;
+        }
+        if (pUo && w.npi) *pUo = u_app;
+        pSm += d6; pSp += d6; pPm += d36; pPp += d36;
+        if (pKg) pKg += d6;
+        if (pUo) pUo += dn;
+        if (pIn) pIn += d1;
 #pragma unroll
         for (int q = 0; q < M; q++) sk_minus[q] = sk_next[q];
-        w_advance(wk);
-        __syncthreads();
-    }
-    if (k_end < T) {             // hand-over to the next time segment (wk now points at filter step k_end)
-        w_store_vec(a.S_MINUS, wk.o6, wk.z6, w, sk_minus);
-        bst(w_at(a.P_MINUS, wk.o36, wk.z36), w.s36, 0u, Pm);
     }
 }
 
@@ -365,88 +403,113 @@ struct WaveBwdIn {
     double u, Pp, Pm1, X;
     int rk;
 };
-// inputs of smoother step k: `wk` points at the array position of filter step k, `w1` at that of step k + 1
-EPI_DEV void w_bwd_fetch(const KArgs &a, const WaveLane &w, const WaveWalk &wk, long s1, unsigned vu, WaveBwdIn &o)
+// this lane's pointers at the array positions of filter step k (S+, P+, u) and k + 1 (S-, P-, X, rank word)
+struct WaveBwdPtr {
+    const double *Sp, *Sm1, *Pp, *Pm1, *X, *u;
+    const int32_t *rk;
+};
+EPI_DEV void w_bwd_fetch(const WaveBwdPtr &q, unsigned blk, const WaveLane &w, WaveBwdIn &o)
 {
-    // s1 = +1 / -1: where step k + 1 sits relative to step k on the caller's time axis
-    w_load_vec(a.S_PLUS, wk.o6, wk.z6, w, o.Sp);
-    w_load_vec(a.S_MINUS, wk.o6 + s1 * (long)wk.z6, wk.z6, w, o.Sm1);
-    o.Pp = bld(w_at(a.P_PLUS, wk.o36, wk.z36), w.v36, 0u);
-    o.Pm1 = bld(w_at(a.P_MINUS, wk.o36 + s1 * (long)wk.z36, wk.z36), w.v36, 0u);
-    // X is stored packed (upper triangle, column by column): element (i, j), i <= j, at row i + j (j + 1) / 2
-    o.X = bld(w_at(a.X, wk.o21 + s1 * (long)wk.z21, wk.z21), w.v21, 0u);
-    o.rk = __builtin_amdgcn_raw_buffer_load_b32(w_at(a.rankbuf, wk.o1i + s1 * (long)wk.z1i, wk.z1i), w.v1i, 0u, 0);
-    o.u = w_load_u(a, wk.ou, wk.zu, vu);
+    w_get_vec(q.Sp, blk, o.Sp);
+    w_get_vec(q.Sm1, blk, o.Sm1);
+    o.Pp = *q.Pp;
+    o.Pm1 = *q.Pm1;
+    o.X = *q.X;
+    o.rk = *q.rk;
+    o.u = w_load_u(q.u, w);
 }
 
 template <int FLIP>
 __global__ __launch_bounds__(kWave) void eks_bwd_wave(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
-    __shared__ double sP[kWave], sT[kWave], sA[kWE], sX[kWave], sJ[kWave], sV[8], sGa[kNpi], sTt[kWave];
+    __shared__ double sP[kWave], sT[kWave], sA[kWave], sX[kWave], sJ[kWave], sGa[kNpi], sTt[kWave];
     if (*dense_flag) return;
     const int c = a.c0 + (int)blockIdx.x;
     if (c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
-    const WaveLane w = w_lane(a, lay);
+    const WaveLane w = w_lane(a);
     const unsigned lane = threadIdx.x;
+    const int tr_b = (w.j + 6 * w.i) * 4;
     QPrm p;
     WaveNpi np;
     w_load_prm(p, np, a, B, c, w, sGa);
-    if (w.own) sA[w.e] = 0.0;
-    const unsigned vu = (unsigned)su * 8u + (unsigned)w.k * (unsigned)a.Su * 8u;
+    const WaveJac jc = w_jac_setup<FLIP>(p, w);
+    const unsigned blk = lay.blk;
+    const long bp = (long)lay.bp;
+    const long dir = FLIP ? 1L : -1L;                    // the smoother walks DOWN the filter's time axis
+    const int lo = w.i < w.j ? w.i : w.j, hi = w.i < w.j ? w.j : w.i;
 
     // terminal condition :189-202
-    WaveWalk wk = w_walk(a, lay, tpos<FLIP>(T - 1, T), FLIP ? 1 : -1);      // the walk runs DOWN the filter's time axis
+    const int tT = tpos<FLIP>(T - 1, T);
     double Ss[M], Ps;
-    w_load_vec(a.S_PLUS, wk.o6, wk.z6, w, Ss);
+    w_get_vec(a.S_PLUS + w_elem(lay, tT, 6u, 0u), blk, Ss);
 #pragma unroll
     for (int i = 0; i < M; i++) {
         const double f = a.s_final[(size_t)i * B + c];
         if (!is_nan(f)) Ss[i] = f;
     }
-    Ps = bld(w_at(a.P_PLUS, wk.o36, wk.z36), w.v36, 0u);
+    Ps = a.P_PLUS[w_elem(lay, tT, 36u, (unsigned)w.e)];
     {
         const double f = a.Ps_final[(size_t)w.e * B + c];
         if (!is_nan(f)) Ps = f;
     }
-    w_store_vec(a.S_SMOOTH, wk.o6, wk.z6, w, Ss);
-    if (a.u_opt_smooth) bst(w_at(a.u_opt_smooth, wk.on, wk.zn), w.sn, 0u, 0.0);      // column T is never written :95,204
-    if (a.pinv_rank) __builtin_amdgcn_raw_buffer_store_b32(-1, w_at(a.pinv_rank, wk.o1i, wk.z1i), w.s1i, 0u, 0);
-    if (a.P_SMOOTH) bst(w_at(a.P_SMOOTH, wk.o36, wk.z36), w.s36, 0u, Ps);
+    double *pSs = a.S_SMOOTH ? a.S_SMOOTH + w_elem(lay, tT, 6u, 0u) : nullptr;
+    double *pPs = a.P_SMOOTH ? a.P_SMOOTH + w_elem(lay, tT, 36u, (unsigned)w.e) : nullptr;
+    double *pUs = a.u_opt_smooth ? a.u_opt_smooth + w_elem(lay, tT, (unsigned)a.n_npi, (unsigned)w.k) : nullptr;
+    int32_t *pRk = a.pinv_rank ? a.pinv_rank + lay_scalar(tT, lay) : nullptr;
+    if (w.first) {
+        if (pSs) w_put_vec(pSs, blk, Ss);
+        if (pRk) *pRk = -1;
+    }
+    if (pUs && w.npi) *pUs = 0.0;                        // column T is never written :95,204
+    if (pPs && w.own) *pPs = Ps;
+    const long d6 = dir * 6 * bp, d36 = dir * 36 * bp, d21 = dir * 21 * bp, dn = dir * (long)a.n_npi * bp, d1 = dir * bp;
+    const long du = dir * (long)a.n_npi * a.Su;
 
     int st_guard = 0, st_cap = 0, min_rank = M;
-    const long s1 = FLIP ? -1L : 1L;
     WaveBwdIn nxt;
-    w_advance(wk);                                       // -> filter step T - 2
-    if (T >= 2) w_bwd_fetch(a, w, wk, s1, vu, nxt);
+    WaveBwdPtr q;
+    if (T >= 2) {
+        const int t = tpos<FLIP>(T - 2, T);              // step k = T - 2; step k + 1 sits at tT
+        q.Sp = a.S_PLUS + w_elem(lay, t, 6u, 0u); q.Sm1 = a.S_MINUS + w_elem(lay, tT, 6u, 0u);
+        q.Pp = a.P_PLUS + w_elem(lay, t, 36u, (unsigned)w.e); q.Pm1 = a.P_MINUS + w_elem(lay, tT, 36u, (unsigned)w.e);
+        // X is stored packed (upper triangle, column by column): element (i, j), i <= j, at row i + j (j + 1) / 2
+        q.X = a.X + w_elem(lay, tT, 21u, (unsigned)(lo + hi * (hi + 1) / 2));
+        q.rk = a.rankbuf + lay_scalar(tT, lay);
+        q.u = a.u + ((size_t)t * a.n_npi + (size_t)w.k) * a.Su + su;
+        w_bwd_fetch(q, blk, w, nxt);
+    }
     for (int k = T - 2; k >= 0; k--) {
         const WaveBwdIn cur = nxt;
-        const WaveWalk here = wk;
-        w_advance(wk);
-        if (k > 0) w_bwd_fetch(a, w, wk, s1, vu, nxt);
+        if (pSs) pSs += d6;
+        if (pPs) pPs += d36;
+        if (pUs) pUs += dn;
+        if (pRk) pRk += d1;
+        if (k > 0) {
+            q.Sp += d6; q.Sm1 += d6; q.Pp += d36; q.Pm1 += d36; q.X += d21; q.rk += d1; q.u += du;
+            w_bwd_fetch(q, blk, w, nxt);
+        }
 
-        // the Jacobian at S+(k) with the ORIGINAL control column :206
+        // the Jacobian at S+(k) with the ORIGINAL control column :206 -- every entry by its owner
         double u_unused, tterm;
         w_npi(p, np, cur.u, cur.Sp[5], u_unused, tterm);
+        const double myA = w_jac_entry(p, jc, cur.Sp);
         __syncthreads();
         sTt[lane] = tterm;
+        sA[lane] = myA;
         sP[lane] = cur.Pp; sX[lane] = cur.X;
-        __syncthreads();
-        double A[M * M];
-        jacobian_entries<M, FLIP>(p, cur.Sp, w_slope<FLIP>(sTt), A);
-        w_put_jacobian(sA, A);
         __syncthreads();
         double J = 0.0;
         int rank = -1;
         if (cur.rk < 0) {                                                // non-finite P_MINUS guard :211-213
             st_guard = 1;
         } else {
-            double pprow[6], arow_j[6];
+            double pprow[6], arow_i[6], arow_j[6];
             w_row(sP, w.i, pprow);
-            w_row(sA, w.j, arow_j);
+            w_jac_rows(sA, w, w_slope<FLIP>(sTt), arow_i, arow_j);
             const double PAt = w_dot6(pprow, arow_j);                    // (P+ A')(i,j) = sum_q P+(i,q) A(j,q)
             sT[lane] = PAt;
             __syncthreads();
@@ -461,7 +524,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd_wave(const KArgs a, const int *
         // S_SMOOTH(k) = clamp(S+ + J (S_SMOOTH(k+1) - S-(k+1)))   :218-221
         double dv[M];
 #pragma unroll
-        for (int q = 0; q < M; q++) dv[q] = Ss[q] - cur.Sm1[q];
+        for (int qq = 0; qq < M; qq++) dv[qq] = Ss[qq] - cur.Sm1[qq];
         __syncthreads();
         sJ[lane] = J;
         const double D = cur.Pm1 - Ps;                                   // D = P_MINUS(k+1) - P_SMOOTH(k+1)
@@ -472,14 +535,12 @@ __global__ __launch_bounds__(kWave) void eks_bwd_wave(const KArgs a, const int *
         w_row(sJ, w.j, jrow_j);
         w_col(sT, w.j, dcol);
         const double Jd_i = w_dot6(jrow_i, dv);
-        if (w.j == 0) sV[w.i] = Jd_i;
         const double T1 = w_dot6(jrow_i, dcol);                          // (J D)(i,j)
-        __syncthreads();
         sP[lane] = T1;
         __syncthreads();
         double Sn[M];
 #pragma unroll
-        for (int q = 0; q < M; q++) Sn[q] = cur.Sp[q] + sV[q];
+        for (int qq = 0; qq < M; qq++) Sn[qq] = cur.Sp[qq] + w_bcast(Jd_i, qq);   // lane q holds (J d)(q)
         state_hard_margins<M>(p, Sn);
         // u_opt_smooth(:, k) = the control NlinStateUpdate applies at S_SMOOTH(k)   :229
         double u_s, t_unused;
@@ -488,17 +549,16 @@ __global__ __launch_bounds__(kWave) void eks_bwd_wave(const KArgs a, const int *
         w_row(sP, w.i, t1row);
         const double T2 = w_dot6(t1row, jrow_j);                         // (J D J')(i,j)
         double Pn = cur.Pp - T2;                                         // :223
-        __syncthreads();
-        sT[lane] = Pn;
-        __syncthreads();
-        Pn = (Pn + sT[w.j + 6 * w.i]) / 2.0;                             // :226
+        Pn = (Pn + w_from(Pn, tr_b)) / 2.0;                              // :226
         Ps = Pn;
 #pragma unroll
-        for (int q = 0; q < M; q++) Ss[q] = Sn[q];
-        w_store_vec(a.S_SMOOTH, here.o6, here.z6, w, Ss);
-        if (a.u_opt_smooth) bst(w_at(a.u_opt_smooth, here.on, here.zn), w.sn, 0u, u_s);
-        if (a.pinv_rank) __builtin_amdgcn_raw_buffer_store_b32(rank, w_at(a.pinv_rank, here.o1i, here.z1i), w.s1i, 0u, 0);
-        if (a.P_SMOOTH) bst(w_at(a.P_SMOOTH, here.o36, here.z36), w.s36, 0u, Ps);
+        for (int qq = 0; qq < M; qq++) Ss[qq] = Sn[qq];
+        if (w.first) {
+            if (pSs) w_put_vec(pSs, blk, Ss);
+            if (pRk) *pRk = rank;
+        }
+        if (pUs && w.npi) *pUs = u_s;
+        if (pPs && w.own) *pPs = Ps;
     }
-    if (threadIdx.x == 0 && a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+    if (w.first && a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }
