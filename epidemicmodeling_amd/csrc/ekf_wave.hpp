@@ -562,3 +562,417 @@ __global__ __launch_bounds__(kWave) void eks_bwd_wave(const KArgs a, const int *
     }
     if (w.first && a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
 }
+
+// =====================================================================================================================
+// 3-state generic models (SIAlphaModelEKF, SIAlphaModelBackwardEKF): SEVEN chains per wavefront, nine lanes each
+// =====================================================================================================================
+// Lane = 9 g + e: group g (0..6) is one chain, e = i + 3 j owns element (i, j) of its 3 x 3 matrices; lane 63 idles.  The
+// chain's state, gain and C are replicated in the nine lanes of its group (no longer wave-uniform, so single-lane values
+// travel by ds_bpermute from the owner instead of v_readlane); lane e also owns NPI e, and lanes e < 3 NPI 9 + e as well.
+// The 3-state models have no free controls (SIAlphaModelEKF.m:39 returns u as it came), so the NPI lanes only form
+// u_max(k) - u(k) for the fma chain of the alpha map.  Same dense, k-ascending products as above: bit for bit the one-lane
+// kernels' and the oracle's results.
+constexpr int kW3G = 7, kW3E = 9;
+
+struct Wave3Lane {
+    int g, e, i, j, c;         // group, element, row, column, chain
+    int base;                  // first lane of the group
+    bool own, lead, live;      // owns an element of a real chain / first lane of such a group / chain exists
+};
+EPI_DEV Wave3Lane w3_lane(const KArgs &a)
+{
+    Wave3Lane w;
+    const int lane = (int)threadIdx.x;
+    w.g = lane < kW3G * kW3E ? lane / kW3E : kW3G - 1;
+    w.e = lane < kW3G * kW3E ? lane - w.g * kW3E : 0;
+    w.j = w.e / 3; w.i = w.e - 3 * w.j;
+    w.base = w.g * kW3E;
+    const int c = a.c0 + (int)blockIdx.x * kW3G + w.g;
+    w.live = c < a.c0 + a.cn;
+    w.c = w.live ? c : a.c0 + a.cn - 1;          // idle groups mirror the last chain: everything they compute is dropped
+    w.own = w.live && lane < kW3G * kW3E;
+    w.lead = w.own && w.e == 0;
+    return w;
+}
+EPI_DEV void w3_row(const double *t, int r, double (&o)[3]) { o[0] = t[r]; o[1] = t[r + 3]; o[2] = t[r + 6]; }
+EPI_DEV void w3_col(const double *t, int c, double (&o)[3]) { o[0] = t[3 * c]; o[1] = t[3 * c + 1]; o[2] = t[3 * c + 2]; }
+EPI_DEV double w3_dot(const double (&x)[3], const double (&y)[3]) { return fma(x[2], y[2], fma(x[1], y[1], x[0] * y[0])); }
+EPI_DEV void w3_put_vec(double *p, unsigned blk, const double (&v)[3])
+{
+#pragma unroll
+    for (int q = 0; q < 3; q++) p[(size_t)q * blk] = v[q];
+}
+EPI_DEV void w3_get_vec(const double *p, unsigned blk, double (&v)[3])
+{
+#pragma unroll
+    for (int q = 0; q < 3; q++) v[q] = p[(size_t)q * blk];
+}
+// my entry of the 3 x 3 Jacobian (SIAlphaModelEKF.m:62-76, Backward...m:83-97): jacobian_entries<3>'s expressions
+struct Wave3Jac { bool x0, x1, y0, y1, s2, neg, base1, cst; double c; };
+template <int FLIP>
+EPI_DEV Wave3Jac w3_jac_setup(const QPrm &p, const Wave3Lane &w)
+{
+    struct E { unsigned char kind, x, y, neg, base1; };       // kind 0 zero, 1 S1, 2 S2, 3 CONST (see WaveJac)
+    const E tab[9] = {/*(0,0)*/ {1, 2, 1, 1, 1}, /*(1,0)*/ {1, 1, 2, 0, 0}, /*(2,0)*/ {0, 0, 0, 0, 0},
+                      /*(0,1)*/ {1, 2, 0, 1, 0}, /*(1,1)*/ {2, 0, 0, 0, 1}, /*(2,1)*/ {0, 0, 0, 0, 0},
+                      /*(0,2)*/ {1, 0, 1, 1, 0}, /*(1,2)*/ {1, 0, 1, 0, 0}, /*(2,2)*/ {3, 0, 0, 1, 1}};
+    E me = tab[0];
+#pragma unroll
+    for (int q = 1; q < 9; q++)
+        if (w.e == q) me = tab[q];
+    Wave3Jac j;
+    j.x0 = me.x == 0; j.x1 = me.x == 1; j.y0 = me.y == 0; j.y1 = me.y == 1;
+    j.s2 = me.kind == 2;
+    j.neg = (me.neg != 0) != (FLIP != 0);
+    j.base1 = me.base1 != 0;
+    j.cst = me.kind == 0 || me.kind == 3;
+    const double dg = p.dt * p.gamma;
+    j.c = me.kind == 3 ? (j.neg ? 1.0 - dg : 1.0 + dg) : 0.0;
+    return j;
+}
+EPI_DEV double w3_jac_entry(const QPrm &p, const Wave3Jac &j, const double (&s)[3])
+{
+    const double w2 = p.dt * (s[0] * s[2] - p.beta);
+    const double X = j.x0 ? s[0] : (j.x1 ? s[1] : s[2]);
+    const double Y = j.y0 ? s[0] : (j.y1 ? s[1] : s[2]);
+    double v = p.dt * X * Y;
+    v = j.s2 ? w2 : v;
+    v = j.neg ? -v : v;
+    const double r = j.base1 ? 1.0 + v : v;
+    return j.cst ? j.c : r;
+}
+struct Wave3Npi { double umax0, umax1; const double *pu0, *pu1; bool two; };   // NPI e, and NPI 9 + e for e < 3
+EPI_DEV void w3_load_prm(QPrm &p, Wave3Npi &n, const KArgs &a, int B, const Wave3Lane &w, double *sGa)
+{
+    const int c = w.c;
+    auto g = [&](int f) { return a.prm[(size_t)f * B + c]; };
+    p.dt = g(EPI_PRM_DT); p.beta = g(EPI_PRM_BETA); p.gamma = g(EPI_PRM_GAMMA);
+    p.sigma = g(EPI_PRM_SIGMA); p.b = g(EPI_PRM_B); p.epsilon = g(EPI_PRM_EPSILON);
+    p.slo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_S_MIN);
+    p.ilo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_I_MIN);
+    p.alpha_min = g(EPI_PRM_ALPHA_MIN); p.alpha_max = g(EPI_PRM_ALPHA_MAX);
+    n.two = w.e < 3;
+    n.umax0 = g(EPI_PRM_U_MAX + w.e);
+    n.umax1 = n.two ? g(EPI_PRM_U_MAX + 9 + w.e) : 0.0;
+    sGa[w.g * kNpi + w.e] = p.gamma * g(EPI_PRM_A + w.e);           // gamma * a(k): the constant factors of the alpha map's fma chain
+    if (n.two) sGa[w.g * kNpi + 9 + w.e] = p.gamma * g(EPI_PRM_A + 9 + w.e);
+}
+// u(k, t): rows beyond n_npi read as 0.0 (the padding of load_u)
+EPI_DEV void w3_load_u(const KArgs &a, const Wave3Npi &n, const Wave3Lane &w, double &u0, double &u1)
+{
+    u0 = (w.e < a.n_npi) ? *n.pu0 : 0.0;
+    u1 = (n.two && 9 + w.e < a.n_npi) ? *n.pu1 : 0.0;
+}
+
+template <int FLIP>
+__global__ __launch_bounds__(kWave) void ekf_fwd_wave3(const KArgs a, const int *__restrict__ dense_flag)
+{
+    constexpr int M = 3;
+    __shared__ double sP[kWave], sT[kWave], sA[kWave], sGa[kW3G * kNpi], sD[kW3G * kNpi];
+    if (*dense_flag) return;
+    const Wave3Lane w = w3_lane(a);
+    const int B = a.B, T = a.T, c = w.c;
+    const int sx = a.x_series ? a.x_series[c] : c;
+    const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    const unsigned lane = threadIdx.x;
+    double *tP = sP + w.base, *tT = sT + w.base, *tA = sA + w.base;
+    const double *tGa = sGa + w.g * kNpi, *tD = sD + w.g * kNpi;
+    const int tr_b = (w.base + w.j + 3 * w.i) * 4;
+
+    QPrm p;
+    Wave3Npi np;
+    w3_load_prm(p, np, a, B, w, sGa);
+    const Wave3Jac jc = w3_jac_setup<FLIP>(p, w);
+    const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
+    const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
+
+    double sk_minus[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) sk_minus[i] = a.s_init[(size_t)i * B + c];
+    double Pm = a.Ps_init[(size_t)w.e * B + c];
+    const double Qe = a.Q[(size_t)w.e * B + c];
+
+    const int k_begin = a.k_begin, k_end = (a.k_end > 0 && a.k_end < T) ? a.k_end : T;
+    const int t0 = tpos<FLIP>(k_begin, T);
+    const long dir = FLIP ? -1L : 1L;
+    const long bp = (long)lay.bp;
+    const unsigned blk = lay.blk;
+    double *pSm = a.S_MINUS ? a.S_MINUS + w_elem(lay, t0, 3u, 0u) : nullptr, *pSp = a.S_PLUS + w_elem(lay, t0, 3u, 0u);
+    double *pKg = a.K_GAIN ? a.K_GAIN + w_elem(lay, t0, 3u, 0u) : nullptr;
+    double *pPm = a.P_MINUS + w_elem(lay, t0, 9u, (unsigned)w.e), *pPp = a.P_PLUS + w_elem(lay, t0, 9u, (unsigned)w.e);
+    double *pUo0 = a.u_opt ? a.u_opt + w_elem(lay, t0, (unsigned)a.n_npi, (unsigned)w.e) : nullptr;
+    double *pUo1 = a.u_opt ? a.u_opt + w_elem(lay, t0, (unsigned)a.n_npi, (unsigned)(9 + w.e)) : nullptr;
+    double *pIn = a.innovations ? a.innovations + lay_scalar(t0, lay) : nullptr;
+    const long d3 = dir * 3 * bp, d9 = dir * 9 * bp, dn = dir * (long)a.n_npi * bp, d1 = dir * bp;
+    np.pu0 = a.u + ((size_t)t0 * a.n_npi + (size_t)(w.e < a.n_npi ? w.e : 0)) * a.Su + su;
+    np.pu1 = a.u + ((size_t)t0 * a.n_npi + (size_t)(9 + w.e < a.n_npi ? 9 + w.e : 0)) * a.Su + su;
+    const long du = dir * (long)a.n_npi * a.Su;
+    const long dx = dir * a.Sx;
+    const double *px = a.x + (size_t)t0 * a.Sx + sx, *pr = a.R_series + (size_t)k_begin * a.Sx + sx;
+    const bool st0 = w.e < a.n_npi && w.own, st1 = np.two && 9 + w.e < a.n_npi && w.own;
+    if (k_begin > 0) {
+        w3_get_vec(pSm, blk, sk_minus);
+        Pm = *pPm;
+    } else {
+        if (w.lead && pSm) w3_put_vec(pSm, blk, sk_minus);
+        if (w.own) *pPm = Pm;
+    }
+    double x_nxt = *px, r_nxt = *pr, u0_nxt, u1_nxt;
+    w3_load_u(a, np, w, u0_nxt, u1_nxt);
+
+    for (int k = k_begin; k < k_end; k++) {
+        const double Rk = r_nxt, xk = x_nxt, u0 = u0_nxt, u1 = u1_nxt;
+        if (k + 1 < T) {
+            px += dx; pr += a.Sx; np.pu0 += du; np.pu1 += du;
+            x_nxt = *px; r_nxt = *pr;
+            w3_load_u(a, np, w, u0_nxt, u1_nxt);
+        }
+        double C[M];
+        obs_jacobian<M>(a.mf, sk_minus, C);                              // :115
+        const double xk_minus = predict_obs<M>(a.mf, sk_minus, v_bar);   // :116-119
+        double innov, K[M], sk_plus[M], Pp;
+        const bool valid = !is_nan(xk);                                  // :122 (per chain: the groups of a wave may differ)
+        // the LDS tiles are exchanged by all groups together, whatever their chains' observations say
+        tP[w.e] = Pm;
+        __syncthreads();
+        {
+            double prow[3], pcol[3];
+            w3_row(tP, w.i, prow);
+            w3_col(tP, w.j, pcol);
+            const double PCt_i = w3_dot(prow, C);                        // (P C')(i)
+            const double CP_j = fma(C[2], pcol[2], fma(C[1], pcol[1], C[0] * pcol[0]));   // (C P)(j)
+            double CP[3];
+#pragma unroll
+            for (int q = 0; q < M; q++) CP[q] = w_from(CP_j, (w.base + 3 * q) * 4);     // lane (0, q) of my group holds (C P)(q)
+            const double CPCt = fma(CP[2], C[2], fma(CP[1], C[1], CP[0] * C[0]));
+            const double den = CPCt + gamma * Rk;                        // :124
+            const double K_i = PCt_i / den, K_j = CP_j / den;            // P(k|k-1) bit-wise symmetric: (C P)(j) == (P C')(j)
+            double ikc_i[3], ikc_j[3];
+#pragma unroll
+            for (int q = 0; q < M; q++) {
+                ikc_i[q] = ((w.i == q) ? 1.0 : 0.0) - K_i * C[q];
+                ikc_j[q] = ((w.j == q) ? 1.0 : 0.0) - K_j * C[q];
+            }
+            const double T1 = w3_dot(ikc_i, pcol);                       // ((I - K C) P)(i,j)
+            tT[w.e] = T1;
+            __syncthreads();
+            double Kv[3];
+#pragma unroll
+            for (int q = 0; q < M; q++) Kv[q] = w_from(K_i, (w.base + q) * 4);          // lane (q, 0) holds K(q)
+            double t1row[3];
+            w3_row(tT, w.i, t1row);
+            const double T2 = w3_dot(t1row, ikc_j);                      // Joseph form :127
+            const double Pv = (T2 + (K_i * Rk) * K_j) / gamma;
+            innov = valid ? xk - xk_minus : 0.0;
+            Pp = valid ? Pv : Pm;                                        // :130-135 when the observation is missing
+#pragma unroll
+            for (int q = 0; q < M; q++) {
+                K[q] = valid ? Kv[q] : 0.0;
+                sk_plus[q] = valid ? sk_minus[q] + Kv[q] * innov : sk_minus[q];        // :129
+            }
+        }
+        state_hard_margins<M>(p, sk_plus);                               // :141
+        const double myA = w3_jac_entry(p, jc, sk_plus);
+        Pp = (Pp + w_from(Pp, tr_b)) / 2.0;                              // :138
+        __syncthreads();
+        tP[w.e] = Pp;
+        tA[w.e] = myA;
+        sD[w.g * kNpi + w.e] = np.umax0 - u0;                            // u_opt == u for the 3-state models
+        if (np.two) sD[w.g * kNpi + 9 + w.e] = np.umax1 - u1;
+        __syncthreads();
+
+        double sk_next[M];
+        {
+            double arow_i[3], arow_j[3], ppcol[3];
+            w3_row(tA, w.i, arow_i);
+            w3_row(tA, w.j, arow_j);
+            w3_col(tP, w.j, ppcol);
+            const double T1 = w3_dot(arow_i, ppcol);                     // (A P+)(i,j)
+            tT[w.e] = T1;
+            const double dot = w_dot_npi(tGa, tD);
+            state_map<M, FLIP>(p, dot, sk_plus, sk_next);
+            __syncthreads();
+            double t1row[3];
+            w3_row(tT, w.i, t1row);
+            double Pn = w3_dot(t1row, arow_j) + Qe;                      // (A P+ A')(i,j) + Q
+            Pn = (Pn + w_from(Pn, tr_b)) / 2.0;                          // :161
+            Pm = Pn;
+        }
+        state_hard_margins<M>(p, sk_next);                               // :164
+
+        const bool more = k + 1 < T;
+        if (w.lead) {
+            w3_put_vec(pSp, blk, sk_plus);
+            if (pKg) w3_put_vec(pKg, blk, K);
+            if (pIn) *pIn = innov;
+            if (more && pSm) w3_put_vec(pSm + d3, blk, sk_next);
+        }
+        if (w.own) {
+            *pPp = Pp;
+            if (more) pPm[d9] = Pm;
+        }
+        if (pUo0) {
+            if (st0) *pUo0 = u0;
+            if (st1) *pUo1 = u1;
+            pUo0 += dn; pUo1 += dn;
+        }
+        if (pSm) pSm += d3;
+        pSp += d3; pPm += d9; pPp += d9;
+        if (pKg) pKg += d3;
+        if (pIn) pIn += d1;
+#pragma unroll
+        for (int q = 0; q < M; q++) sk_minus[q] = sk_next[q];
+    }
+}
+
+struct Wave3BwdIn { double Sp[3], Sm1[3], u0, u1, Pp, Pm1, X; int rk; };
+struct Wave3BwdPtr { const double *Sp, *Sm1, *Pp, *Pm1, *X; const int32_t *rk; };
+
+template <int FLIP>
+__global__ __launch_bounds__(kWave) void eks_bwd_wave3(const KArgs a, const int *__restrict__ dense_flag)
+{
+    constexpr int M = 3;
+    __shared__ double sP[kWave], sT[kWave], sA[kWave], sX[kWave], sJ[kWave], sGa[kW3G * kNpi];
+    if (*dense_flag) return;
+    const Wave3Lane w = w3_lane(a);
+    const int B = a.B, T = a.T, c = w.c;
+    const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    double *tP = sP + w.base, *tT = sT + w.base, *tA = sA + w.base, *tX = sX + w.base, *tJ = sJ + w.base;
+    const int tr_b = (w.base + w.j + 3 * w.i) * 4;
+    QPrm p;
+    Wave3Npi np;
+    w3_load_prm(p, np, a, B, w, sGa);
+    const Wave3Jac jc = w3_jac_setup<FLIP>(p, w);
+    const unsigned blk = lay.blk;
+    const long bp = (long)lay.bp;
+    const long dir = FLIP ? 1L : -1L;
+    const int lo = w.i < w.j ? w.i : w.j, hi = w.i < w.j ? w.j : w.i;
+
+    const int tT_ = tpos<FLIP>(T - 1, T);
+    double Ss[M], Ps;
+    w3_get_vec(a.S_PLUS + w_elem(lay, tT_, 3u, 0u), blk, Ss);
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const double f = a.s_final[(size_t)i * B + c];
+        if (!is_nan(f)) Ss[i] = f;
+    }
+    Ps = a.P_PLUS[w_elem(lay, tT_, 9u, (unsigned)w.e)];
+    {
+        const double f = a.Ps_final[(size_t)w.e * B + c];
+        if (!is_nan(f)) Ps = f;
+    }
+    double *pSs = a.S_SMOOTH ? a.S_SMOOTH + w_elem(lay, tT_, 3u, 0u) : nullptr;
+    double *pPs = a.P_SMOOTH ? a.P_SMOOTH + w_elem(lay, tT_, 9u, (unsigned)w.e) : nullptr;
+    double *pUs0 = a.u_opt_smooth ? a.u_opt_smooth + w_elem(lay, tT_, (unsigned)a.n_npi, (unsigned)w.e) : nullptr;
+    double *pUs1 = a.u_opt_smooth ? a.u_opt_smooth + w_elem(lay, tT_, (unsigned)a.n_npi, (unsigned)(9 + w.e)) : nullptr;
+    int32_t *pRk = a.pinv_rank ? a.pinv_rank + lay_scalar(tT_, lay) : nullptr;
+    const bool st0 = w.e < a.n_npi && w.own, st1 = np.two && 9 + w.e < a.n_npi && w.own;
+    if (w.lead) {
+        if (pSs) w3_put_vec(pSs, blk, Ss);
+        if (pRk) *pRk = -1;
+    }
+    if (pUs0) {
+        if (st0) *pUs0 = 0.0;                            // column T is never written :95,204
+        if (st1) *pUs1 = 0.0;
+    }
+    if (pPs && w.own) *pPs = Ps;
+    const long d3 = dir * 3 * bp, d9 = dir * 9 * bp, d6 = dir * 6 * bp, dn = dir * (long)a.n_npi * bp, d1 = dir * bp;
+    const long du = dir * (long)a.n_npi * a.Su;
+
+    int st_guard = 0, st_cap = 0, min_rank = M;
+    Wave3BwdIn nxt;
+    Wave3BwdPtr q;
+    auto fetch = [&](Wave3BwdIn &o) {
+        w3_get_vec(q.Sp, blk, o.Sp);
+        w3_get_vec(q.Sm1, blk, o.Sm1);
+        o.Pp = *q.Pp; o.Pm1 = *q.Pm1; o.X = *q.X; o.rk = *q.rk;
+        w3_load_u(a, np, w, o.u0, o.u1);
+    };
+    if (T >= 2) {
+        const int t = tpos<FLIP>(T - 2, T);
+        q.Sp = a.S_PLUS + w_elem(lay, t, 3u, 0u);
+        // fp32-storage runs keep no S_MINUS; this shape is fp64 only, S_MINUS always exists
+        q.Sm1 = a.S_MINUS + w_elem(lay, tT_, 3u, 0u);
+        q.Pp = a.P_PLUS + w_elem(lay, t, 9u, (unsigned)w.e); q.Pm1 = a.P_MINUS + w_elem(lay, tT_, 9u, (unsigned)w.e);
+        q.X = a.X + w_elem(lay, tT_, 6u, (unsigned)(lo + hi * (hi + 1) / 2));
+        q.rk = a.rankbuf + lay_scalar(tT_, lay);
+        np.pu0 = a.u + ((size_t)t * a.n_npi + (size_t)(w.e < a.n_npi ? w.e : 0)) * a.Su + su;
+        np.pu1 = a.u + ((size_t)t * a.n_npi + (size_t)(9 + w.e < a.n_npi ? 9 + w.e : 0)) * a.Su + su;
+        fetch(nxt);
+    }
+    for (int k = T - 2; k >= 0; k--) {
+        const Wave3BwdIn cur = nxt;
+        if (pSs) pSs += d3;
+        if (pPs) pPs += d9;
+        if (pUs0) { pUs0 += dn; pUs1 += dn; }
+        if (pRk) pRk += d1;
+        if (k > 0) {
+            q.Sp += d3; q.Sm1 += d3; q.Pp += d9; q.Pm1 += d9; q.X += d6; q.rk += d1; np.pu0 += du; np.pu1 += du;
+            fetch(nxt);
+        }
+        const double myA = w3_jac_entry(p, jc, cur.Sp);                  // :206 (the 3 x 3 Jacobian does not depend on u)
+        __syncthreads();
+        tA[w.e] = myA;
+        tP[w.e] = cur.Pp; tX[w.e] = cur.X;
+        __syncthreads();
+        const bool guard = cur.rk < 0;                                   // non-finite P_MINUS guard :211-213 (per chain)
+        double J;
+        {
+            double pprow[3], arow_j[3];
+            w3_row(tP, w.i, pprow);
+            w3_row(tA, w.j, arow_j);
+            const double PAt = w3_dot(pprow, arow_j);                    // (P+ A')(i,j)
+            tT[w.e] = PAt;
+            __syncthreads();
+            double parow[3], xcol[3];
+            w3_row(tT, w.i, parow);
+            w3_col(tX, w.j, xcol);
+            J = guard ? 0.0 : w3_dot(parow, xcol);                       // :215
+        }
+        int rank = -1;
+        if (guard) st_guard = 1;
+        else {
+            rank = cur.rk & 0xff;
+            st_cap |= (cur.rk >> 8) & 1;
+            min_rank = rank < min_rank ? rank : min_rank;
+        }
+        double dv[M];
+#pragma unroll
+        for (int qq = 0; qq < M; qq++) dv[qq] = Ss[qq] - cur.Sm1[qq];
+        __syncthreads();
+        tJ[w.e] = J;
+        tT[w.e] = cur.Pm1 - Ps;                                          // D = P_MINUS(k+1) - P_SMOOTH(k+1)
+        __syncthreads();
+        double jrow_i[3], jrow_j[3], dcol[3];
+        w3_row(tJ, w.i, jrow_i);
+        w3_row(tJ, w.j, jrow_j);
+        w3_col(tT, w.j, dcol);
+        const double Jd_i = w3_dot(jrow_i, dv);
+        const double T1 = w3_dot(jrow_i, dcol);                          // (J D)(i,j)
+        tP[w.e] = T1;
+        __syncthreads();
+        double Sn[M];
+#pragma unroll
+        for (int qq = 0; qq < M; qq++) Sn[qq] = cur.Sp[qq] + w_from(Jd_i, (w.base + qq) * 4);   // lane (q, 0) holds (J d)(q)
+        state_hard_margins<M>(p, Sn);                                    // :218-221
+        double t1row[3];
+        w3_row(tP, w.i, t1row);
+        double Pn = cur.Pp - w3_dot(t1row, jrow_j);                      // :223
+        Pn = (Pn + w_from(Pn, tr_b)) / 2.0;                              // :226
+        Ps = Pn;
+#pragma unroll
+        for (int qq = 0; qq < M; qq++) Ss[qq] = Sn[qq];
+        if (w.lead) {
+            if (pSs) w3_put_vec(pSs, blk, Ss);
+            if (pRk) *pRk = rank;
+        }
+        if (pUs0) {                                                      // :229 -- the 3-state NlinStateUpdate returns u as it came
+            if (st0) *pUs0 = cur.u0;
+            if (st1) *pUs1 = cur.u1;
+        }
+        if (pPs && w.own) *pPs = Ps;
+    }
+    if (w.lead && a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+}

@@ -960,7 +960,18 @@ static bool monitor_hoisted(const epi_batch_desc *d)
 static int shape_of(const epi_batch_desc *d, int dev)
 {
     const ModelInfo &mi = MODEL_TABLE[d->model];
-    if (mi.m != 6 || !mi.generic || d->storage) return EPI_SHAPE_LANE;
+    if (!mi.generic || d->storage) return EPI_SHAPE_LANE;
+    if (mi.m == 3) {
+        // 3-state models: seven chains per wavefront, nine lanes each (ekf_fwd_wave3), for small batches; otherwise one lane
+        // per chain.  There is no four-lane shape for them.  Measured (BASELINE config 3's chains x 400 days, ms per pass,
+        // wave / lane): 300 chains 0.91 / 1.04, 2 000 1.09 / 1.20, 7 000 1.47 / 1.26, 20 000 3.08 / 1.80 -- a 3-state step is
+        // bound by its scalar chain (state map, the 12-term NPI sum, two divisions: ~1.4 us per day in EITHER shape), the
+        // 3 x 3 algebra the wave shape spreads over nine lanes is a small part of it.  Chosen up to 2 048 chains.
+        const bool ok = monitor_hoisted(d);
+        if (d->shape == EPI_SHAPE_WAVE) return ok ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
+        if (d->shape == EPI_SHAPE_LANE || d->shape == EPI_SHAPE_QUAD) return EPI_SHAPE_LANE;
+        return (ok && d->B <= 2048) ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
+    }
     const bool wave_ok = monitor_hoisted(d);
     if (d->shape == EPI_SHAPE_WAVE) return wave_ok ? EPI_SHAPE_WAVE : EPI_SHAPE_QUAD;
     if (d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_LANE) return d->shape;
@@ -1078,6 +1089,13 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
                 done = true;
             }
         }
+        if constexpr (M == 3 && GENERIC) {
+            if (ka.wave) {          // seven chains per wavefront, nine lanes each
+                hipLaunchKernelGGL((ekf_fwd_wave3<FLIP>), dim3((unsigned)((ka.B + kW3G - 1) / kW3G)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                done = true;
+            }
+        }
         if constexpr (M == 6 && GENERIC) {
             if (ka.quad && !done) {
                 // four lanes per chain, 16 chains per wavefront (ekf_quad.hpp): the specialisation for the layout and the
@@ -1156,6 +1174,12 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
         if constexpr (M == 6 && GENERIC) {
             if (ka.wave) {
                 hipLaunchKernelGGL((eks_bwd_wave<FLIP>), dim3((unsigned)ka.B), dim3(kWave), 0, st, ka, ka.dense_flag);
+                done = true;
+            }
+        }
+        if constexpr (M == 3 && GENERIC) {
+            if (ka.wave) {
+                hipLaunchKernelGGL((eks_bwd_wave3<FLIP>), dim3((unsigned)((ka.B + kW3G - 1) / kW3G)), dim3(kWave), 0, st, ka, ka.dense_flag);
                 done = true;
             }
         }

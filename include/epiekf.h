@@ -152,7 +152,9 @@ typedef struct epi_batch_desc {
                              every 6 x 6 matrix, operands exchanged through LDS; the shortest per-day latency, for batches of
                              at most one chain per SIMD -- the reference's own one-call-per-cost-weight loop; needs R_v as a
                              per-day series, else falls back to 2).  Auto: 3 up to 1024 chains, 2 up to 16 384, then 1.
-                             Results are bit-identical in all shapes.  Ignored by the other models. */
+                             The 3-state generic models know 1 and 3 (there: SEVEN chains per wavefront, nine lanes each,
+                             ekf_fwd_wave3 / eks_bwd_wave3; auto: 3 up to 2 048 chains).  Results are bit-identical in all
+                             shapes.  Ignored by the NewCase models. */
     int32_t storage;      /* element type of the OUTPUT arrays: 0 = fp64 (the reference's), 1 = fp32 storage with fp64
                              register arithmetic (BASELINE config 5): every selected output is the fp64 result rounded
                              once to fp32; the forward quantities the smoother reads back stay fp64 in the workspace.

@@ -32,10 +32,13 @@ del src, dst
 # `python traffic_probe.py shard`: the 9 375-chain shard one of 8 GPUs runs (four lanes per chain) instead of the whole sweep;
 # `live`: the living multi-wave epidemic (bench.py --workload cfg4-live); `reduced`: the two outputs the caller consumes
 args = set(sys.argv[1:])
-w = synth.make_cfg4(75, 125, live="live" in args) if "shard" in args else synth.make_cfg4(live="live" in args)
+if "wave250" in args:             # a region's 250 cost weights: the one-wavefront-per-chain shape (round 4)
+    w = synth.make_cfg4(1, 250)
+else:
+    w = synth.make_cfg4(75, 125, live="live" in args) if "shard" in args else synth.make_cfg4(live="live" in args)
 outs = ["u_opt_smooth", "S_SMOOTH"] if "reduced" in args else None
 r = batch.EkfRunner(batch.DeviceWorkload(w, dev), outputs=outs, lane_block="auto")   # bench.py's default layout and lane mapping
-for _ in range(2):
+for _ in range(20 if "wave250" in args else 2):
     for ph in (1, 3, 4):
         r.run(phase=ph)
 torch.cuda.synchronize()
