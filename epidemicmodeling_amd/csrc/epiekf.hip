@@ -1837,7 +1837,11 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     epi_batch_desc d = *d0;
     const size_t Bfull = (size_t)d0->B;
     d.B = n;
-    d.exact_nonfinite = 1;     // a host call returns what the dense evaluation returns, overflowed chains included
+    // A host call returns what the dense evaluation returns, overflowed chains included (exact_nonfinite) -- but the call ends
+    // with a synchronising download anyway, so the per-chain status words come back with it and the dense second pass is
+    // enqueued only when one of them has bit 0 set: the common call pays nothing for it (the device-side variant costs five
+    // launches that return at once, ~40 us of a 1.5 ms one-chain call).
+    d.exact_nonfinite = 0;
     const bool id_x = !in->x_series, id_u = !in->u_series;      // identity series: one series per chain, sliced with the chains
     if (id_x) d.Sx = n;
     if (id_u) d.Su = n;
@@ -1877,8 +1881,19 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     for (auto &o : olist)
         o_out.push_back(((d.out_mask & o.bit) && o.host) ? io.add_out(o.host, o.rows, 8, Bfull, lo, n) : (size_t)-1);
     const size_t o_rank = out->pinv_rank ? io.add_out(out->pinv_rank, T, 4, Bfull, lo, n) : (size_t)-1;
-    const size_t o_stat = out->status ? io.add_out(out->status, 1, 4, Bfull, lo, n) : (size_t)-1;
-    const size_t wsb = epi_ekf_workspace_bytes(&d);
+    // does this call run the smoother (which is where an overflowed chain is recognised)?
+    const uint32_t smooth_bits = EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH | (mi.generic ? (uint32_t)EPI_OUT_U_OPT_SMOOTH : 0u);
+    bool smooths = out->pinv_rank != nullptr || out->status != nullptr;
+    for (auto &o : olist) smooths = smooths || ((d.out_mask & o.bit & smooth_bits) && o.host);
+    const bool watch = smooths && mi.generic && d.q_mode == 0 && d.storage == 0 && d.phase == 0;
+    std::vector<int32_t> own_status;
+    int32_t *hstat = out->status ? out->status + lo : nullptr;
+    size_t o_stat = (size_t)-1;
+    if (out->status) o_stat = io.add_out(out->status, 1, 4, Bfull, lo, n);
+    else if (watch) { own_status.assign((size_t)n, 0); hstat = own_status.data(); o_stat = io.add_out(own_status.data(), 1, 4, (size_t)n, 0, n); }
+    epi_batch_desc dmax = d;
+    dmax.exact_nonfinite = watch ? 1 : 0;            // the workspace is sized for the second pass
+    const size_t wsb = epi_ekf_workspace_bytes(&dmax);
     const size_t o_ws = io.reserve(wsb);
     hipError_t e = cx->reserve(io.off + 256);
     if (e != hipSuccess) return hip_fail(err, e, "device arena");
@@ -1904,6 +1919,15 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     const int rc = epi_ekf_run_device(&d, &din, &dout, wsb ? base + o_ws : nullptr, wsb, cx->stream, err);
     if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
     if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download");
+    if (watch) {
+        bool any = false;
+        for (int c = 0; c < n; c++) any = any || (hstat[c] & 1);
+        if (any) {                                    // rare: a covariance overflowed -- the dense second pass, then the outputs again
+            const int rc2 = epi_ekf_run_device(&dmax, &din, &dout, wsb ? base + o_ws : nullptr, wsb, cx->stream, err);
+            if (rc2 != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc2; }
+            if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download (dense second pass)");
+        }
+    }
     return EPI_OK;
 }
 static int host_args_ok(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, char *err)

@@ -166,7 +166,10 @@ typedef struct epi_batch_desc {
                              an overflow they may carry a finite number where MATLAB has NaN.  Generic models, full call
                              (phase 0), fixed Q_w, fp64 storage; costs three launches that return at once when no chain is
                              marked (~0.15 ms at 75 000 x 520) and needs (B + 1 + B) more int32 of workspace.  The *_host
-                             entry points always set it.  0: as the kernels leave them (`status` still tells which chains). */
+                             entry points give the same result at no cost to the common call: epi_ekf_run_host[_multi] look at
+                             the status words that come back with the outputs and enqueue the second pass only when a chain is
+                             marked (calls that select a smoothed output, pinv_rank or status); epi_sweep_prescribe_host sets
+                             the flag.  0: as the kernels leave them (`status` still tells which chains). */
 } epi_batch_desc;
 
 typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3 } epi_shape;
