@@ -67,7 +67,7 @@ EPI_DEV void load_sym(const double *__restrict__ src, int t, const Lay &l, doubl
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) P[sidx(i, j)] = bld(r, voff, (unsigned)IXM(i, j) * rowb);
+        for (int i = 0; i <= j; i++) P[sidx(i, j)] = bld_s(r, voff, (unsigned)IXM(i, j) * rowb);
 }
 
 // ---------------------------------------------------------------------------
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
         unsigned voff, rowb;
         const rsrc_t r = lay_slice(a.X, tpos<FLIP>(k + 1, T), NS, lay, voff, rowb);
 #pragma unroll
-        for (int e = 0; e < NS; e++) d.X[e] = bld(r, voff, (unsigned)e * rowb);
+        for (int e = 0; e < NS; e++) d.X[e] = bld_s(r, voff, (unsigned)e * rowb);
     };
     int t_pend = -1, rank_pend = -1;
     double u_pend[kNpi];

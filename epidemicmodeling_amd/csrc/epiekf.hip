@@ -110,9 +110,30 @@ EPI_DEV double bld(rsrc_t r, unsigned voff, unsigned soff)
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
+// Cache policy of the big streams (aux bit 1 = `nt` on gfx950).  Every output is written once and read back -- if at all --
+// tens of GB later, so the stores are NON-TEMPORAL: they do not push the shared input series, the model constants and the
+// smoother's own read stream out of L2 / Infinity Cache.  Measured on the headline sweep, alternating builds on one box
+// (round 4): 17.4-18.0 -> 16.3-17.0 ms per pass (smoother 8.0 -> 7.3 ms, forward kernel -0.2 ms), reduced outputs 13.7 -> 13.4,
+// nothing slower.  Non-temporal LOADS on every load: 20.3 ms (the shared series stop being cached) -- so only the streams a launch
+// reads exactly once (the stored forward quantities and X in the smoothers, P_MINUS in the pinv grid) are loaded `nt` (bld_s):
+// another 16.2-17.0 -> 15.8-16.1 ms, the next pass's forward kernel finding its shared inputs still in cache.
+#ifndef EPI_ST_AUX
+#define EPI_ST_AUX 2
+#endif
+#ifndef EPI_ST32_AUX
+#define EPI_ST32_AUX 2            // the fp32-storage twins of the stores (BASELINE config 5): 16.9 -> 16.7 ms
+#endif
+#ifndef EPI_LD_STREAM_AUX
+#define EPI_LD_STREAM_AUX 2
+#endif
 EPI_DEV void bst(rsrc_t r, unsigned voff, unsigned soff, double v)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, EPI_ST_AUX);
+}
+// a load of data that this launch reads exactly once (stored forward quantities, X)
+EPI_DEV double bld_s(rsrc_t r, unsigned voff, unsigned soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, EPI_LD_STREAM_AUX));
 }
 EPI_DEV double ldg(const double *__restrict__ row, unsigned voff)
 {
@@ -178,7 +199,7 @@ EPI_DEV void load_vec(const double *__restrict__ src, int t, const Lay &l, doubl
     unsigned voff, rowb;
     const rsrc_t r = lay_slice(src, t, M, l, voff, rowb);
 #pragma unroll
-    for (int i = 0; i < M; i++) v[i] = bld(r, voff, (unsigned)i * rowb);
+    for (int i = 0; i < M; i++) v[i] = bld_s(r, voff, (unsigned)i * rowb);
 }
 template <int M>
 EPI_DEV void load_mat(const double *__restrict__ src, int t, const Lay &l, double (&P)[M * M])
@@ -186,7 +207,7 @@ EPI_DEV void load_mat(const double *__restrict__ src, int t, const Lay &l, doubl
     unsigned voff, rowb;
     const rsrc_t r = lay_slice(src, t, M * M, l, voff, rowb);
 #pragma unroll
-    for (int e = 0; e < M * M; e++) P[e] = bld(r, voff, (unsigned)e * rowb);
+    for (int e = 0; e < M * M; e++) P[e] = bld_s(r, voff, (unsigned)e * rowb);
 }
 // full symmetric matrix from a packed upper-triangle array (M(M+1)/2 rows)
 template <int M>
@@ -199,7 +220,7 @@ EPI_DEV void load_packed(const double *__restrict__ src, int t, const Lay &l, do
     for (int j = 0; j < M; j++)
 #pragma unroll
         for (int i = 0; i <= j; i++) {
-            const double v = bld(r, voff, (unsigned)(i + j * (j + 1) / 2) * rowb);
+            const double v = bld_s(r, voff, (unsigned)(i + j * (j + 1) / 2) * rowb);
             P[IXM(i, j)] = v;
             P[IXM(j, i)] = v;
         }
@@ -240,7 +261,7 @@ EPI_DEV rsrc_t lay_slice_f32(const float *p, int t, unsigned rows, const Lay &l,
 }
 EPI_DEV void bst32(rsrc_t r, unsigned voff, unsigned soff, double v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)v), r, voff, soff, EPI_ST32_AUX);
 }
 template <int N>
 EPI_DEV void store_rows_f32(float *__restrict__ dst, int t, unsigned rows, const Lay &l, const double (&v)[N])
@@ -437,12 +458,27 @@ constexpr int pinv_wg() { return M >= 6 ? 64 : 256; }
 template <int M>
 __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
 {
-    // grid: x = pinv_wg<M>()-chain tiles of the chain range, y = step; a workgroup shares one step => uniform row bases
-    const int cl = blockIdx.x * blockDim.x + threadIdx.x;
+    // grid: x = pinv_wg<M>()-chain tiles of the chain range (rounded up to a multiple of 8), y = step; a workgroup shares one
+    // step => uniform row bases
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear-id order, so
+    // XCD c gets ids c, c + 8, ...  Within EVERY step give each XCD a contiguous eighth of the tiles: neighbouring tiles --
+    // whose 64 chains share a partial cache line where they straddle a 40-chain layout block -- then meet in one L2, and all
+    // XCDs still walk the steps together (the early, full-rank steps cost three times the late ones).
+    const unsigned gx = gridDim.x;
+    const unsigned long long lin = (unsigned long long)blockIdx.y * gx + blockIdx.x;      // (2^17 tiles x 2^16 steps exceed 32 bits)
+    const unsigned per = gx >> 3;                              // tiles of a step per XCD (the grid's x extent is a multiple of 8)
+    const unsigned xcd = (unsigned)(lin & 7ull);
+    const unsigned long long k = lin >> 3;
+    unsigned by = blockIdx.y, bx = blockIdx.x;                 // fewer than 8 tiles: the launch keeps the plain order
+    if ((gx & 7u) == 0u) {
+        by = (unsigned)(k / per);
+        bx = xcd * per + (unsigned)(k - (unsigned long long)by * per);
+    }
+    const int cl = (int)(bx * blockDim.x + threadIdx.x);
     if (cl >= a.cn) return;
     const int B = a.B;
     // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
-    const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)blockIdx.y;
+    const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)by;
     const int c = a.c0 + cl;
     if (a.only && !a.only[c]) return;
     const Lay lay = make_lay(a, c);
@@ -454,7 +490,7 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
 #pragma unroll
     for (int j = 0; j < M; j++)
 #pragma unroll
-        for (int i = 0; i <= j; i++) Pu[i + j * (j + 1) / 2] = bld(rp, voff_p, (unsigned)IXM(i, j) * rowb_p);
+        for (int i = 0; i <= j; i++) Pu[i + j * (j + 1) / 2] = bld_s(rp, voff_p, (unsigned)IXM(i, j) * rowb_p);
     bool bad = false;                                      // :211
 #pragma unroll
     for (int i = 0; i < NSX; i++) bad = bad || is_nonfinite(Pu[i]);
@@ -1156,7 +1192,9 @@ static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st)
 {
     if (nsteps <= 0) return hipSuccess;
     ka.c0 = 0; ka.cn = ka.B; ka.pinv_step0 = step0;
-    hipLaunchKernelGGL((eks_pinv<M>), dim3((unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>()), (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
+    // x extent rounded up to a multiple of 8: the kernel re-orders its tiles so that every XCD gets a contiguous eighth per step
+    const unsigned tiles = (unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>());
+    hipLaunchKernelGGL((eks_pinv<M>), dim3(tiles >= 8u ? ((tiles + 7u) & ~7u) : tiles, (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
     return hipGetLastError();
 }
 
