@@ -42,25 +42,35 @@ rep["sweep_prescribe_host_300x250x520"] = {
     "note": "per-region inputs expanded on the device; filter + scoring + Pareto filter + gather of the optimum's plan; python packing of the ctypes call included"}
 print(json.dumps(rep["sweep_prescribe_host_300x250x520"]), flush=True)
 
+def timed(w, n, **kw):
+    """median / min ms of the C call alone (output arrays of the first call written again) and of the python call that
+    allocates and NaN-fills fresh output arrays every time (what a MEX gateway's mxCreateDoubleMatrix costs as well)"""
+    out = H.host_call(w, **kw)
+    tc, tw = [], []
+    for _ in range(n):
+        H.host_call(w, out=out, timing=tc, **kw)
+    for _ in range(max(3, n // 2)):
+        t0 = time.perf_counter(); H.host_call(w, **kw); tw.append(time.perf_counter() - t0)
+    mb = sum(v.nbytes for v in out.values()) / 1e6
+    return {"c_call_ms_median": 1e3 * float(np.median(tc)), "c_call_ms_min": 1e3 * min(tc),
+            "with_fresh_output_arrays_ms_median": 1e3 * float(np.median(tw)), "device_to_host_MB": mb,
+            "c_call_GB_per_s_of_outputs": mb / 1e3 / float(np.median(tc))}
+
+
 full = synth.make_cfg4(75, 125, 400, 120)                         # 9 375 chains
-H.host_call(full, devices=[0], outputs=["u_opt_smooth", "S_SMOOTH"], extras=False)
-ts = []
-for _ in range(5):
-    t0 = time.perf_counter(); H.host_call(full, devices=[0], outputs=["u_opt_smooth", "S_SMOOTH"], extras=False); ts.append(time.perf_counter() - t0)
-rep["run_host_multi_9375_chains_reduced_outputs"] = {"ms_median": 1e3 * float(np.median(ts)), "ms_min": 1e3 * min(ts),
-                                                     "device_to_host_MB": 9375 * 520 * 18 * 8 / 1e6,
-                                                     "note": "epi_ekf_run_host_multi, one block on device 0; 702 MB of selected outputs over PCIe into pageable memory"}
-print(json.dumps(rep["run_host_multi_9375_chains_reduced_outputs"]), flush=True)
+for tag, devs in (("one_block", [0]), ("two_blocks_strided", [0, 0])):
+    r = timed(full, 5, devices=devs, outputs=["u_opt_smooth", "S_SMOOTH"], extras=False)
+    r["note"] = ("epi_ekf_run_host_multi, 9 375 chains (the shard of the sweep one of 8 GPUs runs), reduced outputs into pageable memory; "
+                 + ("one block on device 0" if len(devs) == 1 else "two chain blocks, both on device 0, one after the other: every array is moved as a strided piece"))
+    rep["run_host_multi_9375_chains_reduced_outputs_" + tag] = r
+    print(json.dumps(r), flush=True)
 
 two = synth.make_cfg4(2, 250, 400, 120)
 for tag, w in (("B1", two.select(np.array([137]))), ("B250", two.select(np.arange(250)))):
-    H.host_call(w, extras=False)
-    ts = []
-    for _ in range(9):
-        t0 = time.perf_counter(); H.host_call(w, extras=False); ts.append(time.perf_counter() - t0)
+    r = timed(w, 9, extras=False)
     t0 = time.perf_counter(); H.oracle_batch(w, n_threads=1); t_cpu = time.perf_counter() - t0
-    rep["run_host_" + tag] = {"chains": w.B, "days": w.T, "gpu_call_ms_median": 1e3 * float(np.median(ts)), "gpu_call_ms_min": 1e3 * min(ts),
-                              "cpu_oracle_one_thread_ms": 1e3 * t_cpu, "note": "all 11 outputs; python packing of the ctypes call included (~0.1 ms)"}
-    print(json.dumps(rep["run_host_" + tag]), flush=True)
+    r.update({"chains": w.B, "days": w.T, "cpu_oracle_one_thread_ms": 1e3 * t_cpu, "note": "epi_ekf_run_host, all 11 outputs"})
+    rep["run_host_" + tag] = r
+    print(json.dumps(r), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "host_calls.json"), "w"), indent=1)

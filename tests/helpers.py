@@ -198,16 +198,20 @@ def lapack_reading_worker(job):
     return out
 
 
-def host_call(w, devices=None, outputs=None, extras=True, shape=0):
+def host_call(w, devices=None, outputs=None, extras=True, shape=0, out=None, timing=None):
     """Workload `w` through the HOST-pointer C ABI (classic layout, numpy arrays [T][rows][B]): epi_ekf_run_host on device
-    0, or -- devices = list of device ids -- epi_ekf_run_host_multi with one chain block per entry.  Returns dict of arrays."""
+    0, or -- devices = list of device ids -- epi_ekf_run_host_multi with one chain block per entry.  Returns dict of arrays.
+    `out`: the dict a previous call returned (its arrays are written again instead of allocating and NaN-filling new ones);
+    `timing`: a list that gets the seconds the C call itself took appended."""
     import ctypes as C
+    import time
     from epidemicmodeling_amd import _lib
     names = [n for n in (outputs or OUT_NAMES) if not (w.model.startswith("NewCase") and n == "u_opt_smooth")]
     m, n_npi, B, T = w.m, w.n_npi, w.B, w.T
     rows = {"u_opt": n_npi, "u_opt_smooth": n_npi, "S_MINUS": m, "S_PLUS": m, "S_SMOOTH": m, "P_MINUS": m * m, "P_PLUS": m * m,
             "P_SMOOTH": m * m, "K_GAIN": m}
-    out = {k: np.full((T, rows[k], B) if k in rows else (T, B), np.nan) for k in names}
+    if out is None:
+        out = {k: np.full((T, rows[k], B) if k in rows else (T, B), np.nan) for k in names}
     mask = 0
     for k in names:
         mask |= L.OUT_BITS[k]
@@ -228,14 +232,18 @@ def host_call(w, devices=None, outputs=None, extras=True, shape=0):
     for k in names:
         setattr(outs, k, out[k].ctypes.data)
     if extras:
-        out["pinv_rank"] = np.full((T, B), -7, dtype=np.int32); out["status"] = np.full((B,), -7, dtype=np.int32)
+        if "pinv_rank" not in out:
+            out["pinv_rank"] = np.full((T, B), -7, dtype=np.int32); out["status"] = np.full((B,), -7, dtype=np.int32)
         outs.pinv_rank, outs.status = out["pinv_rank"].ctypes.data, out["status"].ctypes.data
     err = C.create_string_buffer(256)
+    t0 = time.perf_counter()
     if devices is None:
         rc = _lib.lib().epi_ekf_run_host(C.byref(d), C.byref(ins), C.byref(outs), 0, err)
     else:
         ids = (C.c_int * len(devices))(*devices)
         rc = _lib.lib().epi_ekf_run_host_multi(C.byref(d), C.byref(ins), C.byref(outs), len(devices), ids, err)
+    if timing is not None:
+        timing.append(time.perf_counter() - t0)
     _lib.check(rc, err)
     return out
 
