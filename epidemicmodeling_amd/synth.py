@@ -97,7 +97,7 @@ class Workload:
             Ps_init=np.ascontiguousarray(self.Ps_init[:, chains]),
             s_final=np.ascontiguousarray(self.s_final[:, chains]),
             Ps_final=np.ascontiguousarray(self.Ps_final[:, chains]),
-            Q=np.ascontiguousarray(self.Q[:, chains]),
+            Q=np.ascontiguousarray(self.Q[..., chains]),     # [m*m][B], or [T][m*m][B] when Q_w varies in time
             L=self.L, order=self.order, obs_type=self.obs_type, meta=dict(self.meta))
 
 

@@ -56,7 +56,34 @@ CASES = {
     "ref_sia3_backward_120": (lambda: synth.as_backward(synth.make_cfg3(60, 120)), np.array([0, 31, 59]), np.zeros(0, dtype=np.int64)),
     "ref_sia6_backward_40": (lambda: synth.as_backward(synth.make_cfg4(6, 10, 30, 10)), np.array([0, 27, 59]), np.zeros(0, dtype=np.int64)),
     "ref_newcase_sweep_400_120": (lambda: synth.make_newcase_sweep(), _sweep_chains((0, 157), (10, 187)), np.zeros(0, dtype=np.int64)),
+    # added later in round 4: the axes the first eight do not touch -- the 6-state time-flipped wrapper over a longer series,
+    # the TOTALCASES observation, a time-varying Q_w (the DENSE kernels' route) and fully specified terminal conditions
+    "ref_sia6_backward_150": (lambda: synth.as_backward(synth.make_cfg4(6, 10, 120, 30)), np.array([0, 27, 59]), np.zeros(0, dtype=np.int64)),
+    "ref_sia3_totalcases_200": (lambda: _totalcases(synth.make_cfg3(60, 200)), np.array([0, 31, 59]), np.zeros(0, dtype=np.int64)),
+    "ref_cfg4_varying_q_90_30": (lambda: H.with_time_varying_q(synth.make_cfg4(4, 6, 90, 30)), np.array([0, 9, 17, 23]), np.zeros(0, dtype=np.int64)),
+    "ref_cfg3_terminal_120": (lambda: _with_terminal(synth.make_cfg3(30, 120)), np.array([0, 13, 29]), np.zeros(0, dtype=np.int64)),
 }
+
+
+def _totalcases(w):
+    w.obs_type = "TOTALCASES"
+    w.x = np.cumsum(w.x, axis=0)
+    return w
+
+
+def _with_terminal(w, seed=5):
+    """s_final and a symmetric positive definite Ps_final given for every entry (GenericEKF.m:189-202 overrides them all)."""
+    rng = np.random.default_rng(seed)
+    m = w.m
+    w.s_final = np.ascontiguousarray(w.s_init * (0.5 + 0.4 * rng.random(w.s_init.shape)))
+    Pf = np.zeros((m * m, w.B))
+    for c in range(w.B):
+        g = rng.standard_normal((m, m)) * 1e-3
+        S = g @ g.T + 1e-8 * np.eye(m)
+        S = (S + S.T) / 2.0
+        Pf[:, c] = S.reshape(-1, order="F")
+    w.Ps_final = Pf
+    return w
 VEC = ["u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "K_GAIN", "innovations", "rho"]
 MAT = ["P_MINUS", "P_PLUS", "P_SMOOTH"]
 

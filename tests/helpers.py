@@ -249,7 +249,8 @@ def host_call(w, devices=None, outputs=None, extras=True, shape=0, out=None, tim
 
 
 REFEREE_CASES = ["ref_cfg4_dead_400_120", "ref_cfg4_live_400_120", "ref_cfg4_live_60_120", "ref_row3_adaptiveR_30_120",
-                 "ref_cfg3_400", "ref_sia3_backward_120", "ref_sia6_backward_40", "ref_newcase_sweep_400_120"]
+                 "ref_cfg3_400", "ref_sia3_backward_120", "ref_sia6_backward_40", "ref_newcase_sweep_400_120",
+                 "ref_sia6_backward_150", "ref_sia3_totalcases_200", "ref_cfg4_varying_q_90_30", "ref_cfg3_terminal_120"]
 REFEREE_GATE_CAP = 1e-2      # an output whose frozen gate exceeds this is rounding-dominated in fp64: reported, not gated
 
 
