@@ -62,7 +62,7 @@ class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
     def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, time_pipe=0, precheck=True, lane_block=0, shape=0,
-                 storage="f64", exact_nonfinite=False):
+                 storage="f64", exact_nonfinite=False, slab=None):
         """time_pipe: epi_batch_desc.time_pipe (0 = the library decides whether a full call runs its forward kernel in time
         segments with the pinv grid of each segment beside the next, 1 = on, -1 = off).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
@@ -95,17 +95,39 @@ class EkfRunner:
         _lib.check(h.epi_ekf_validate(C.byref(self.desc), self.err), self.err)
         dev = dw.device
         self.out = {}
+        shapes = {}
         for n in names:
             rows = L.out_rows(n, dw.m, dw.n_npi)
             if self.blk == dw.B:
-                shape = (dw.T, dw.B) if rows == 0 else (dw.T, rows, dw.B)
+                shapes[n] = (dw.T, dw.B) if rows == 0 else (dw.T, rows, dw.B)
             else:
-                shape = (dw.T, self.nblk * self.blk) if rows == 0 else (dw.T, self.nblk, rows, self.blk)
-            self.out[n] = torch.empty(shape, dtype=odt, device=dev)
+                shapes[n] = (dw.T, self.nblk * self.blk) if rows == 0 else (dw.T, self.nblk, rows, self.blk)
+        self.ws_bytes = int(h.epi_ekf_workspace_bytes(C.byref(self.desc)))
+        ws_elems = (max(self.ws_bytes, 8) + 7) // 8
+        if slab is None:
+            for n in names:
+                self.out[n] = torch.empty(shapes[n], dtype=odt, device=dev)
+            self.ws = torch.empty(ws_elems, dtype=torch.float64, device=dev)
+        else:
+            # ONE device allocation for every output and the workspace (slab = {"align": bytes, "stagger": bytes}): array i
+            # starts at a multiple of `align` plus i * `stagger` -- the arrays' relative placement is then the caller's choice
+            # instead of the allocator's (profiles/alloc_probe.py)
+            align, stagger = int(slab.get("align", 2 << 20)), int(slab.get("stagger", 0))
+            isz = torch.empty((), dtype=odt).element_size()
+            offs, off = {}, 0
+            for i, n in enumerate(names + ["__ws__"]):
+                nbytes = ws_elems * 8 if n == "__ws__" else int(np.prod(shapes[n])) * isz
+                off = (off + align - 1) // align * align + i * stagger
+                offs[n] = (off, nbytes)
+                off += nbytes
+            self._slab = torch.empty(off, dtype=torch.uint8, device=dev)
+            for n in names:
+                o, nb = offs[n]
+                self.out[n] = self._slab[o:o + nb].view(odt).view(shapes[n])
+            o, nb = offs["__ws__"]
+            self.ws = self._slab[o:o + nb].view(torch.float64)
         self.pinv_rank = torch.empty((dw.T, self.nblk * self.blk), dtype=torch.int32, device=dev) if extras else None
         self.status = torch.zeros((dw.B,), dtype=torch.int32, device=dev) if extras else None
-        self.ws_bytes = int(h.epi_ekf_workspace_bytes(C.byref(self.desc)))
-        self.ws = torch.empty((max(self.ws_bytes, 8) + 7) // 8, dtype=torch.float64, device=dev)
         self.ins = dw.inputs_struct()
         self.desc.time_pipe = int(time_pipe)
         self._sweep = None
