@@ -49,6 +49,16 @@ struct VecLds {
     EPI_DEV double Umax(int k) const { return base[(2 * kNpi + k) * kWave]; }
     EPI_DEV double W(int k) const { return base[(3 * kNpi + k) * kWave]; }
 };
+// The three-state models read a and u_max only (SIAlphaModelEKF.m:39-48: no bang-bang substitution, no slope term), so their
+// packed smoother keeps two 12-vectors per lane in LDS instead of four: 12 KB per 64-lane workgroup instead of 24 KB, which
+// had capped it at six workgroups per CU (1.5 waves per SIMD) where its registers allow two.
+struct VecLds2 {
+    const double *base;   // this lane's column of a [2][12][64] block: a, u_max
+    EPI_DEV double A(int k) const { return base[(0 * kNpi + k) * kWave]; }
+    EPI_DEV double Umax(int k) const { return base[(1 * kNpi + k) * kWave]; }
+    EPI_DEV double Umin(int) const { return 0.0; }     // six-state code only (resolve_control, the slope term)
+    EPI_DEV double W(int) const { return 0.0; }
+};
 struct VecLdsS {          // the same with a run-time lane stride (LDS sized by the lanes a workgroup actually uses)
     const double *base;
     int stride;

@@ -412,7 +412,8 @@ struct BwdIn {   // everything smoother step k reads: forward quantities of step
 template <int M, int FLIP, int STOR = 0>
 __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
-    __shared__ double vlds[4 * kNpi * kWave];   // a, u_min, u_max, w: one column per lane
+    constexpr int NV = (M == 6) ? 4 : 2;        // 6 states: a, u_min, u_max, w; 3 states: a, u_max (VecLds2)
+    __shared__ double vlds[NV * kNpi * kWave];  // one column per lane
     if (*dense_flag) return;
     constexpr int NS = nsym<M>();
     const int lane = threadIdx.x;
@@ -421,15 +422,19 @@ __global__ __launch_bounds__(EPI_BWD_LB) void eks_bwd_sym(const KArgs a, const i
     const int B = a.B, T = a.T;
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
-    LitePrm<VecLds> p;
+    LitePrm<typename std::conditional<M == 6, VecLds, VecLds2>::type> p;
     load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
     p.v.base = vlds + lane;
 #pragma unroll
     for (int k = 0; k < kNpi; k++) {
         vlds[(0 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_A + k) * B + c];
-        vlds[(1 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
-        vlds[(2 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
-        vlds[(3 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+        if constexpr (M == 6) {
+            vlds[(1 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
+            vlds[(2 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
+            vlds[(3 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+        } else {
+            vlds[(1 * kNpi + k) * kWave + lane] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
+        }
     }
 
     double Qd[M];

@@ -554,16 +554,23 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
     const Lay lay = make_lay(a, c);
     // the four 12-vectors of `params` in an LDS column per lane instead of 96 VGPRs (without this the 6-state kernel
     // spills: 512 registers + 84 B of scratch)
-    __shared__ double vlds[4 * kNpi * kWave];
-    LitePrm<VecLds> p;
+    // (three states: a and u_max only, VecLds2 -- 12 KB instead of 24 KB per workgroup, so that LDS does not cap the kernel
+    // below the two waves per SIMD its registers allow)
+    constexpr int NV = (M == 6) ? 4 : 2;
+    __shared__ double vlds[NV * kNpi * kWave];
+    LitePrm<typename std::conditional<M == 6, VecLds, VecLds2>::type> p;
     load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
     p.v.base = vlds + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < kNpi; k++) {
         vlds[(0 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_A + k) * B + c];
-        vlds[(1 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
-        vlds[(2 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
-        vlds[(3 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+        if constexpr (M == 6) {
+            vlds[(1 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
+            vlds[(2 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
+            vlds[(3 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+        } else {
+            vlds[(1 * kNpi + k) * kWave + threadIdx.x] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
+        }
     }
 
     // terminal conditions :189-202
