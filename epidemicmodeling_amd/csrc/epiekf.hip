@@ -117,11 +117,16 @@ EPI_DEV double bld(rsrc_t r, unsigned voff, unsigned soff)
 // nothing slower.  Non-temporal LOADS on every load: 20.3 ms (the shared series stop being cached) -- so only the streams a launch
 // reads exactly once (the stored forward quantities and X in the smoothers, P_MINUS in the pinv grid) are loaded `nt` (bld_s):
 // another 16.2-17.0 -> 15.8-16.1 ms, the next pass's forward kernel finding its shared inputs still in cache.
+// Round 4, later: `nt` + `sc1` (aux 18: non-temporal AND written through at system scope, so the line does not stay dirty
+// in L2) -- level with `nt` alone on boxes / placements where the pass runs at its best (15.5-15.9 ms) and 0.4-0.8 ms faster
+// where the L2's tag pipeline stalls on the concurrently streamed arrays ("where the arrays lie"): forward kernel
+// 7.05 -> 6.67 ms on one box, smoother 7.8 -> 7.0 ms on another, three boxes 16.1-16.9 -> 15.6-15.9 ms per pass.  `sc1` on the
+// stream LOADS as well (aux 18) brings the slow mode back; `sc0 | sc1 | nt` (19) on them is level with `nt` alone.
 #ifndef EPI_ST_AUX
-#define EPI_ST_AUX 2
+#define EPI_ST_AUX 18
 #endif
 #ifndef EPI_ST32_AUX
-#define EPI_ST32_AUX 2            // the fp32-storage twins of the stores (BASELINE config 5): 16.9 -> 16.7 ms
+#define EPI_ST32_AUX 18           // the fp32-storage twins of the stores (BASELINE config 5)
 #endif
 #ifndef EPI_LD_STREAM_AUX
 #define EPI_LD_STREAM_AUX 2

@@ -3,7 +3,7 @@ set -e
 LIBS=$1; shift
 cd $GRAFT_REPO_ROOT/epidemicmodeling_amd
 cp libepiekf.so /tmp/libepiekf_keep.so
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
   for L in $LIBS; do
     cp $L libepiekf.so
     ( cd .. && timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline "$@" 2>/dev/null | python -c "
