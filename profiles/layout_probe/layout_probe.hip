@@ -95,3 +95,32 @@ extern "C" int run_probe_rw(const double *in, double *out, int B, int T, int rro
                        rmode, wmode, work);
     return (int)hipGetLastError();
 }
+
+// Round 4: ONE record per (step, block) against the eight separate arrays the forward kernel writes today (rows 6, 6, 36,
+// 36, 6, 1, 1, 12 of a 40-chain block): the same 104 rows of 320 B per wave and step, plain or non-temporal stores.
+// Run over fresh allocations to see whether the spread between placements (profiles/alloc_probe.py) comes with the number
+// of concurrently written arrays.
+struct Ptr8 { double *p[8]; };
+extern "C" __global__ __launch_bounds__(64) void probe8(Ptr8 a, int B, int T, int blk, int nt)
+{
+    const int rows[8] = {6, 6, 36, 36, 6, 1, 1, 12};
+    const int lane = threadIdx.x, c = blockIdx.x * blk + lane;
+    if (lane >= blk || c >= B) return;
+    double v = c * 1e-9;
+    for (int t = 0; t < T; t++) {
+        v = fma(v, 1.0000001, 1e-12);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            double *p = a.p[k] + ((size_t)t * gridDim.x + blockIdx.x) * rows[k] * blk + lane;
+            if (nt) for (int r = 0; r < rows[k]; r++) __builtin_nontemporal_store(v + r, p + (size_t)r * blk);
+            else for (int r = 0; r < rows[k]; r++) p[(size_t)r * blk] = v + r;
+        }
+    }
+}
+extern "C" int run_probe8(double **ptrs, int B, int T, int blk, int nt, void *stream)
+{
+    Ptr8 a;
+    for (int k = 0; k < 8; k++) a.p[k] = ptrs[k];
+    hipLaunchKernelGGL(probe8, dim3((B + blk - 1) / blk), dim3(64), 0, (hipStream_t)stream, a, B, T, blk, nt);
+    return (int)hipGetLastError();
+}
