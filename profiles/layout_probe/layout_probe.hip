@@ -124,3 +124,30 @@ extern "C" int run_probe8(double **ptrs, int B, int T, int blk, int nt, void *st
     hipLaunchKernelGGL(probe8, dim3((B + blk - 1) / blk), dim3(64), 0, (hipStream_t)stream, a, B, T, blk, nt);
     return (int)hipGetLastError();
 }
+
+// Round 4, BASELINE config 5's forward store pattern (fp32 storage, 3 states, 64-chain blocks): `n` arrays, array k with rows[k]
+// rows of 64 elements of es[k] bytes (4 or 8) per block and step -- today's eight fp32 outputs + three fp64 workspace arrays
+// against variants that fuse arrays into records.  nt stores.
+struct PtrN { void *p[12]; int rows[12]; int es[12]; int n; };
+extern "C" __global__ __launch_bounds__(64) void probeN(PtrN a, int B, int T)
+{
+    const int lane = threadIdx.x, c = blockIdx.x * 64 + lane;
+    if (c >= B) return;
+    double v = c * 1e-9;
+    for (int t = 0; t < T; t++) {
+        v = fma(v, 1.0000001, 1e-12);
+        for (int k = 0; k < a.n; k++) {
+            const size_t base = ((size_t)t * gridDim.x + blockIdx.x) * a.rows[k] * 64 + lane;
+            if (a.es[k] == 8) { double *p = (double *)a.p[k] + base; for (int r = 0; r < a.rows[k]; r++) __builtin_nontemporal_store(v + r, p + (size_t)r * 64); }
+            else { float *p = (float *)a.p[k] + base; for (int r = 0; r < a.rows[k]; r++) __builtin_nontemporal_store((float)(v + r), p + (size_t)r * 64); }
+        }
+    }
+}
+extern "C" int run_probeN(void **ptrs, const int *rows, const int *es, int n, int B, int T, void *stream)
+{
+    PtrN a;
+    a.n = n;
+    for (int k = 0; k < n; k++) { a.p[k] = ptrs[k]; a.rows[k] = rows[k]; a.es[k] = es[k]; }
+    hipLaunchKernelGGL(probeN, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, B, T);
+    return (int)hipGetLastError();
+}

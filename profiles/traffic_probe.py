@@ -34,10 +34,13 @@ del src, dst
 args = set(sys.argv[1:])
 if "wave250" in args:             # a region's 250 cost weights: the one-wavefront-per-chain shape (round 4)
     w = synth.make_cfg4(1, 250)
+elif "cfg5" in args:              # BASELINE config 5: 307 200 3-state chains x 400 days, fp32 storage
+    w = synth.make_cfg5(300, 1024, 400)
 else:
     w = synth.make_cfg4(75, 125, live="live" in args) if "shard" in args else synth.make_cfg4(live="live" in args)
 outs = ["u_opt_smooth", "S_SMOOTH"] if "reduced" in args else None
-r = batch.EkfRunner(batch.DeviceWorkload(w, dev), outputs=outs, lane_block="auto")   # bench.py's default layout and lane mapping
+r = batch.EkfRunner(batch.DeviceWorkload(w, dev), outputs=outs, lane_block="auto",    # bench.py's default layout and lane mapping
+                    storage="f32" if "cfg5" in args else "f64")
 for _ in range(20 if "wave250" in args else 2):
     for ph in (1, 3, 4):
         r.run(phase=ph)
