@@ -151,3 +151,78 @@ extern "C" int run_probeN(void **ptrs, const int *rows, const int *es, int n, in
     hipLaunchKernelGGL(probeN, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, a, B, T);
     return (int)hipGetLastError();
 }
+
+// probeN with the real kernel's constraints: `lds_bytes` of dynamic LDS per workgroup caps the resident waves (20 KB -> 8 per
+// CU = 2 per SIMD), `work` dependent FMAs per step stand for the filter's arithmetic, and `wait` makes every step read one
+// value per lane (from `in`, [T][B]) and use it -- a vector load the wave must wait for once per step, as the filter does.
+extern "C" __global__ __launch_bounds__(64) void probeNW(PtrN a, const double *in, int B, int T, int work, int wait)
+{
+    extern __shared__ double pad[];
+    const int lane = threadIdx.x, c = blockIdx.x * 64 + lane;
+    if (c >= B) return;
+    if (work < 0) pad[lane] = 1.0;
+    double v = c * 1e-9;
+    double nxt = wait ? in[c] : 0.0;
+    for (int t = 0; t < T; t++) {
+        const double cur = nxt;
+        if (wait && t + 1 < T) nxt = in[(size_t)(t + 1) * B + c];
+        v += cur;
+        for (int w = 0; w < work; w++) v = fma(v, 1.0000001, 1e-12);
+        for (int k = 0; k < a.n; k++) {
+            const size_t base = ((size_t)t * gridDim.x + blockIdx.x) * a.rows[k] * 64 + lane;
+            if (a.es[k] == 8) { double *p = (double *)a.p[k] + base; for (int r = 0; r < a.rows[k]; r++) __builtin_nontemporal_store(v + r, p + (size_t)r * 64); }
+            else { float *p = (float *)a.p[k] + base; for (int r = 0; r < a.rows[k]; r++) __builtin_nontemporal_store((float)(v + r), p + (size_t)r * 64); }
+        }
+    }
+}
+extern "C" int run_probeNW(void **ptrs, const int *rows, const int *es, int n, const double *in, int B, int T, int work, int wait,
+                           int lds_bytes, void *stream)
+{
+    PtrN a;
+    a.n = n;
+    for (int k = 0; k < n; k++) { a.p[k] = ptrs[k]; a.rows[k] = rows[k]; a.es[k] = es[k]; }
+    hipLaunchKernelGGL(probeNW, dim3((B + 63) / 64), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, a, in, B, T, work, wait);
+    return (int)hipGetLastError();
+}
+
+// The headline's forward pattern (104 fp64 rows per 40-chain block and step in eight arrays) with arithmetic between the
+// stores and one awaited (cached) load per step, one wave per SIMD (40 KB of LDS per workgroup): 8 B per lane and store (104
+// operations per step, as shipped) against 16 B per lane (row PAIRS interleaved per chain: 52 operations).  A wave may have 63
+// vector-memory operations outstanding; does halving the operations let the arithmetic of the next step overlap the drain?
+extern "C" __global__ __launch_bounds__(64) void probeP(Ptr8 a, const double *in, int B, int T, int blk, int work, int pair)
+{
+    extern __shared__ double pad[];
+    const int rows[8] = {6, 6, 36, 36, 6, 2, 2, 12};      // (the two one-row arrays counted as one two-row array each way)
+    const int lane = threadIdx.x, c = blockIdx.x * blk + lane;
+    if (lane >= blk || c >= B) return;
+    if (work < 0) pad[lane] = 1.0;
+    double v0 = c * 1e-9, v1 = 1.0, v2 = 2.0, v3 = 3.0;
+    double nxt = in[blockIdx.x & 255];
+    for (int t = 0; t < T; t++) {
+        const double cur = nxt;
+        nxt = in[(t + blockIdx.x) & 255];
+        v0 += cur;
+        for (int w = 0; w < work; w += 4) {
+            v0 = fma(v0, 1.0000001, 1e-12); v1 = fma(v1, 1.0000001, 1e-12); v2 = fma(v2, 1.0000001, 1e-12); v3 = fma(v3, 1.0000001, 1e-12);
+        }
+        const double v = (v0 + v1) + (v2 + v3);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (pair) {
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                d2v *p = (d2v *)a.p[k] + ((size_t)t * gridDim.x + blockIdx.x) * (rows[k] / 2) * blk + lane;
+                for (int r = 0; r < rows[k] / 2; r++) { d2v x = {v + r, v - r}; __builtin_nontemporal_store(x, p + (size_t)r * blk); }
+            } else {
+                double *p = a.p[k] + ((size_t)t * gridDim.x + blockIdx.x) * rows[k] * blk + lane;
+                for (int r = 0; r < rows[k]; r++) __builtin_nontemporal_store(v + r, p + (size_t)r * blk);
+            }
+        }
+    }
+}
+extern "C" int run_probeP(double **ptrs, const double *in, int B, int T, int blk, int work, int pair, int lds_bytes, void *stream)
+{
+    Ptr8 a;
+    for (int k = 0; k < 8; k++) a.p[k] = ptrs[k];
+    hipLaunchKernelGGL(probeP, dim3((B + blk - 1) / blk), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, a, in, B, T, blk, work, pair);
+    return (int)hipGetLastError();
+}
