@@ -226,3 +226,46 @@ extern "C" int run_probeP(double **ptrs, const double *in, int B, int T, int blk
     hipLaunchKernelGGL(probeP, dim3((B + blk - 1) / blk), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, a, in, B, T, blk, work, pair);
     return (int)hipGetLastError();
 }
+
+// pair = 2 of the idea above WITHOUT another layout: the wave writes its rows to LDS ([row][lane]) and reads them back
+// transposed -- lanes 0..blk/2-1 take row 2q, lanes blk/2..blk-1 row 2q+1, each TWO neighbouring chains (16 B) -- so that one
+// store covers two rows of the shipped [t][block][row][blk] layout: 53 stores of 16 B per lane instead of 106 of 8 B, the
+// same bytes at the same addresses.
+extern "C" __global__ __launch_bounds__(64) void probeT(Ptr8 a, const double *in, int B, int T, int blk, int work)
+{
+    extern __shared__ double lds[];          // [36][blk] transposition tile (+ padding to cap the occupancy)
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    const int rows[8] = {6, 6, 36, 36, 6, 2, 2, 12};
+    const int lane = threadIdx.x, c = blockIdx.x * blk + lane;
+    if (lane >= blk || c >= B) return;       // (a ragged last block would need the per-row path; not in this probe)
+    const int half = blk / 2, hi = lane >= half ? 1 : 0, pl = lane - hi * half;      // my row of the pair, my chain pair
+    double v0 = c * 1e-9, v1 = 1.0, v2 = 2.0, v3 = 3.0;
+    double nxt = in[blockIdx.x & 255];
+    for (int t = 0; t < T; t++) {
+        const double cur = nxt;
+        nxt = in[(t + blockIdx.x) & 255];
+        v0 += cur;
+        for (int w = 0; w < work; w += 4) {
+            v0 = fma(v0, 1.0000001, 1e-12); v1 = fma(v1, 1.0000001, 1e-12); v2 = fma(v2, 1.0000001, 1e-12); v3 = fma(v3, 1.0000001, 1e-12);
+        }
+        const double v = (v0 + v1) + (v2 + v3);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            for (int r = 0; r < rows[k]; r++) lds[r * blk + lane] = v + r;
+            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed (one wave per workgroup)
+            char *base = (char *)(a.p[k] + ((size_t)t * gridDim.x + blockIdx.x) * rows[k] * blk);
+            for (int q = 0; q < rows[k] / 2; q++) {
+                const int r = 2 * q + hi;
+                const d2v x = *(const d2v *)&lds[r * blk + 2 * pl];
+                __builtin_nontemporal_store(x, (d2v *)(base + ((size_t)r * blk + 2 * pl) * 8));
+            }
+        }
+    }
+}
+extern "C" int run_probeT(double **ptrs, const double *in, int B, int T, int blk, int work, int lds_bytes, void *stream)
+{
+    Ptr8 a;
+    for (int k = 0; k < 8; k++) a.p[k] = ptrs[k];
+    hipLaunchKernelGGL(probeT, dim3((B + blk - 1) / blk), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, a, in, B, T, blk, work);
+    return (int)hipGetLastError();
+}

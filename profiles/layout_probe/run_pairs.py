@@ -27,12 +27,18 @@ xin = torch.rand(256, dtype=torch.float64, device="cuda:0")
 gb = nblk * blk * T * sum(rows) * 8 / 1e9
 for lds, occ in ((40 * 1024 - 256, "1 wave/SIMD"), (0, "all resident")):
     for work in (0, 400, 800, 1600):
-        for pair in (0, 1):
+        for pair in (0, 1, 2):
             ts = []
             for _ in range(4):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(); rc = h.run_probeP(ptrs, C.c_void_p(xin.data_ptr()), B, T, blk, work, pair, lds, C.c_void_p(st.cuda_stream)); b.record()
+                a.record()
+                if pair < 2:
+                    rc = h.run_probeP(ptrs, C.c_void_p(xin.data_ptr()), B, T, blk, work, pair, lds, C.c_void_p(st.cuda_stream))
+                else:       # the shipped layout, rows transposed through LDS into 16-byte stores
+                    rc = h.run_probeT(ptrs, C.c_void_p(xin.data_ptr()), B, T, blk, work, max(lds, 36 * blk * 8), C.c_void_p(st.cuda_stream))
+                b.record()
                 torch.cuda.synchronize(); assert rc == 0
                 ts.append(a.elapsed_time(b))
             t = float(np.median(ts[1:]))
-            print(f"{occ:13s} FMAs/step {work:4d}  {'16 B/lane, 53 stores' if pair else ' 8 B/lane, 106 stores'}  {t:6.2f} ms = {gb / t:.2f} TB/s", flush=True)
+            what = [" 8 B/lane, 106 stores", "16 B/lane, 53 stores (row pairs interleaved)", "16 B/lane, 53 stores (shipped layout, through LDS)"][pair]
+            print(f"{occ:13s} FMAs/step {work:4d}  {what:50s} {t:6.2f} ms = {gb / t:.2f} TB/s", flush=True)
