@@ -128,8 +128,10 @@ EPI_DEV double bld(rsrc_t r, unsigned voff, unsigned soff)
 #ifndef EPI_ST32_AUX
 #define EPI_ST32_AUX 18           // the fp32-storage twins of the stores (BASELINE config 5)
 #endif
+// (`sc0 | sc1 | nt` = 19 on the stream loads: -0.24 +- 0.10 ms per headline pass against `nt` alone over 20 paired runs on four
+// boxes, smoother -0.13, slow outliers 16.6-17.2 -> at most 16.8 ms; `sc1 | nt` = 18 brings the smoother's slow mode back)
 #ifndef EPI_LD_STREAM_AUX
-#define EPI_LD_STREAM_AUX 2
+#define EPI_LD_STREAM_AUX 19
 #endif
 EPI_DEV void bst(rsrc_t r, unsigned voff, unsigned soff, double v)
 {
