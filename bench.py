@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the fixed sweep sharded over the ranks (default); weak = every rank a full sweep "
                          "of its own regions")
-    ap.add_argument("--shape", default="auto", choices=["auto", "lane", "quad", "wave"],
+    ap.add_argument("--shape", default="auto", choices=["auto", "lane", "quad", "wave", "hex"],
                     help="lane mapping of the 6-state kernels (epi_batch_desc.shape): auto = by batch size")
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="f32 = BASELINE config 5's fp32: outputs STORED as float32, arithmetic and the smoother's inputs fp64 "
@@ -411,7 +411,7 @@ def main():
             "scaling": "strong" if (strong or world == 1) and args.scaling == "strong" else "weak",
             "vs_baseline": None, "dtype": "f64" if args.storage == "f64" else "f64 arithmetic, f32 storage", "data": "synthetic",
             "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "time_pipe": args.time_pipe,
-                       "lane_block": runner.blk, "shape": ("wave (one wavefront per chain)" if m == 6 else "wave (seven 9-lane chains per wavefront)") if runner.blk == 1 and w.B > 1 else (("quad (4 lanes per chain)" if runner.blk == 16 else "lane (1 lane per chain)") if m == 6 else "lane (1 lane per chain)"),
+                       "lane_block": runner.blk, "shape": ("wave (one wavefront per chain)" if m == 6 else "wave (seven 9-lane chains per wavefront)") if runner.blk == 1 and w.B > 1 else (("quad (4 lanes per chain)" if runner.blk == 16 else ("hex (6 lanes per chain)" if runner.blk == 10 else "lane (1 lane per chain)")) if m == 6 else "lane (1 lane per chain)"),
                        "sweep_chains_total": B_total,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
                        "historic_only_steps_per_pass_per_gpu": w.B * (t_hist_idx + 1),

@@ -78,7 +78,7 @@ class EkfRunner:
         self.desc = _lib.make_desc(dw.model, dw.B, dw.T, dw.Sx, dw.Su, dw.n_npi, dw.L, dw.order, dw.obs_type,
                                    dw.r_mode, self.mask, dw.q_mode)
         # epi_batch_desc.shape: 0 = by batch size, 1 / 2 = one / four lanes per chain (6-state generic models)
-        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2, "wave": 3}.get(shape, shape)
+        self.desc.shape = {"auto": 0, "lane": 1, "quad": 2, "wave": 3, "hex": 4}.get(shape, shape)
         # epi_batch_desc.storage: "f32" = outputs stored as float32 (each the fp64 result rounded once; BASELINE config 5)
         self.desc.storage = {"f64": 0, "f32": 1}[storage]
         # epi_batch_desc.exact_nonfinite: chains whose covariance overflows are run again by the dense kernels, in place

@@ -1,0 +1,769 @@
+// ekf_hex.hpp -- SIX lanes per chain, TEN chains per wavefront (6-state generic models; epi_batch_desc.shape = 4).
+// Included by epiekf.hip inside namespace epi, after ekf_wave.hpp.
+//
+// Why a fourth shape.  The shard of the headline sweep on one of 8 GPUs is 9 375 chains: with four lanes per chain
+// (ekf_quad.hpp) that is 586 wavefronts on 1 024 SIMDs -- 438 SIMDs idle while every wave works through ~850 / ~730 vector
+// instructions per day (a quarter of them DPP moves of the block exchange, a sixth v_cndmask of lanes that play two roles).
+// The largest number of lanes a chain can have while every wavefront still owns a SIMD is 1 024 * 64 / 9 375 = 6.9: six.
+//
+//   * lane 6 g + j (g = 0..9) owns COLUMN j of every 6 x 6 matrix of chain g of the wavefront; lanes 60..63 idle (they mirror
+//     the last chain into a tile of their own and never store);
+//   * covariances are stored symmetrised (GenericEKF.m:138,161,226: both halves hold the same bits), so column j IS row j.
+//     A product X = L P with the left factor known to every lane (the Jacobian, I - K C: functions of the state, which all
+//     six lanes hold) is formed column by column with no exchange at all, and the second product Y = X L' ROW by row:
+//     Y(j, i) = sum_k X(j, k) L(i, k) needs row j of X -- one transpose through LDS (three ds_write_b128, six ds_read_b64
+//     per lane) -- and again only the replicated factor.  The symmetrisation (Y + Y') / 2 is a second transpose.  No lane
+//     ever needs a whole matrix of another lane's making, except J in the smoother (one all-gather per step);
+//   * since every lane multiplies with the WHOLE Jacobian, its 15 structural zeros are skipped without any per-lane select
+//     (fma(0, x, acc) == acc for finite x: the packed kernels' rule) -- 21 fma per product and lane instead of
+//     the quad shape's 54 + 36 DPP moves;
+//   * every element's fma chain still runs k-ascending in ONE lane: the oracle's rounding sequence, bit for bit;
+//   * the twelve NPIs are handled two per lane; vectors that all lanes need (P C', the gain, u_max - u, the slope terms,
+//     S_SMOOTH) are gathered through eight-double LDS rows.
+// One wavefront per workgroup; LDS exchanges need no barrier (a wave's LDS operations execute in order), only a
+// wavefront-scope fence that keeps the compiler from moving a read above the write it depends on.
+//
+// Inputs: R_v a per-day series (the innovation monitor is replayed by ekf_monitor), fixed diagonal Q_w, fp64 storage --
+// the conditions of the wave shape.  Measured: profiles/r05/batch_size_sweep.txt.
+#pragma once
+
+constexpr int kHL = 6;          // lanes per chain
+constexpr int kHG = 10;         // chains per wavefront
+constexpr int kHGp = 11;        // groups incl. the phantom one of lanes 60..63
+constexpr int kHT = 38;         // doubles per chain in a matrix tile: 36 + 2, i.e. 304 B -- 16-byte aligned, and the b128 reads
+                                // of different chains fall into different banks ((76 g + 4 m) mod 64 = 12 g + 4 m: distinct)
+constexpr int kHV = 8;          // doubles per chain in a 6-vector row
+constexpr int kHN = 12;         // doubles per chain in an NPI row
+
+typedef double hx_d2 __attribute__((ext_vector_type(2)));
+
+struct HexLane {
+    int g, j, c;                // group (chain of the wavefront), column owned, chain
+    bool live;                  // the chain exists: this lane stores
+    unsigned dead;              // added to every store offset: 0, or 3 GiB for a lane that must not store -- beyond any slice
+                                // (a slice is < 2.5 GB: rows * B * 8 with B <= 2^23), so the descriptor's bounds check drops
+                                // the store and no store needs an EXEC-mask branch around it
+};
+EPI_DEV HexLane hx_lane(const KArgs &a)
+{
+    HexLane h;
+    const int lane = (int)threadIdx.x;
+    h.g = lane / kHL;
+    h.j = lane - h.g * kHL;                       // lanes 60..63: group 10, columns 0..3
+    const int c = a.c0 + (int)blockIdx.x * kHG + h.g;
+    h.live = h.g < kHG && c < a.c0 + a.cn;
+    h.c = h.live ? c : a.c0 + a.cn - 1;           // idle groups mirror the last chain: what they compute is dropped
+#ifdef EPI_HEX_NOSTORE           // timing probe: no lane stores anything (results are wrong)
+    h.dead = 0xC0000000u;
+#else
+    h.dead = h.live ? 0u : 0xC0000000u;
+#endif
+    return h;
+}
+// Ordering of the LDS exchanges.  The hardware executes a wave's LDS operations in issue order, so all that is needed is that
+// the compiler keeps a read behind the write it depends on -- and it must, without being told: every exchange has an LDS array of
+// its own, and in each a lane's write (slot j, or element j of a row) and its reads (element j of every slot, or the whole row)
+// overlap for some j, so they may alias and stay in program order; accesses to DIFFERENT exchanges' arrays are free to move,
+// which is what lets a lone wave fill one exchange's latency with the next one's arithmetic.  EPI_HEX_FENCE=1 puts a
+// wavefront-scope fence around every exchange instead (measured slower).
+#ifndef EPI_HEX_FENCE
+#define EPI_HEX_FENCE 0
+#endif
+#ifndef EPI_HEX_BRANCHLESS
+#define EPI_HEX_BRANCHLESS 0
+#endif
+EPI_DEV void hx_fence()
+{
+#if EPI_HEX_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#endif
+}
+
+// The stores of this shape are non-temporal but NOT written through (`sc1`, what the other shapes' stores add): a layout row of
+// ten chains is 80 bytes, so a store instruction's 480 contiguous bytes begin and end inside cache lines that the neighbouring
+// instruction completes -- written through, every such partial line costs a memory transaction of its own (forward kernel of the
+// 9 375-chain shard 1.79 ms with `nt sc1`, 1.53 plain, 1.35 with `nt`, 1.32 with no stores at all).
+EPI_DEV void hst(rsrc_t r, unsigned voff, unsigned soff, double v) { bst_nt(r, voff, soff, v); }
+
+// my six values into slot j of my chain's tile (t = tile + kHT g + 6 j)
+EPI_DEV void hx_put6(double *t, const double (&v)[6])
+{
+    hx_d2 *q = (hx_d2 *)t;
+    q[0] = hx_d2{v[0], v[1]};
+    q[1] = hx_d2{v[2], v[3]};
+    q[2] = hx_d2{v[4], v[5]};
+}
+// element j of every slot (t = tile + kHT g + j): the transposed six
+EPI_DEV void hx_get_tr(const double *t, double (&v)[6])
+{
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = t[6 * i];
+}
+// transpose: lane j gives v (column j, or row j) and receives element j of the six lanes' vectors
+EPI_DEV void hx_transpose(double *tile_g, int j, const double (&v)[6], double (&o)[6])
+{
+    hx_fence();
+    hx_put6(tile_g + 6 * j, v);
+    hx_fence();
+    hx_get_tr(tile_g + j, o);
+}
+// all 36 values of my chain's tile, slot-major: m[6 s + e] = element e of slot s
+EPI_DEV void hx_get_all(const double *tile_g, double (&m)[36])
+{
+    const hx_d2 *q = (const hx_d2 *)tile_g;
+#pragma unroll
+    for (int e = 0; e < 18; e++) {
+        const hx_d2 v = q[e];
+        m[2 * e] = v.x;
+        m[2 * e + 1] = v.y;
+    }
+}
+// v[j] of a replicated 6-vector (j is this lane's column): a select chain on lane predicates.  The operands are made opaque
+// first: hipcc otherwise reads the chain as v[j], i.e. a dynamically indexed array, and moves the vector to scratch.
+EPI_DEV double hx_opaque(double v)
+{
+    asm("" : "+v"(v));
+    return v;
+}
+EPI_DEV double hx_pick(const double (&v)[6], int j)
+{
+    double w[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) w[i] = hx_opaque(v[i]);       // (inside the select's arm the asm would turn the select into a branch)
+    double r = w[0];
+#pragma unroll
+    for (int i = 1; i < 6; i++) r = (j == i) ? w[i] : r;
+    return r;
+}
+
+// ---- per-chain constants ------------------------------------------------------------------------------------------
+struct HexNpi {
+    double a[2], umin[2], umax[2], ew[2], term[2];   // NPIs k = j and j + 6 (see QNpi)
+    double inv_sigma;
+    double ga[kNpi];                                 // gamma * a(k), all twelve: the constant factors of NlinStateUpdate's fma chain
+};
+EPI_DEV void hx_load_prm(QPrm &p, HexNpi &n, const KArgs &a, int B, const HexLane &h)
+{
+    const int c = h.c;
+    auto g = [&](int f) { return a.prm[(size_t)f * B + c]; };
+    p.dt = g(EPI_PRM_DT); p.beta = g(EPI_PRM_BETA); p.gamma = g(EPI_PRM_GAMMA);
+    p.sigma = g(EPI_PRM_SIGMA); p.b = g(EPI_PRM_B); p.epsilon = g(EPI_PRM_EPSILON);
+    p.slo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_S_MIN);
+    p.ilo = a.mf.lo_is_zero ? 0.0 : g(EPI_PRM_I_MIN);
+    p.alpha_min = g(EPI_PRM_ALPHA_MIN); p.alpha_max = g(EPI_PRM_ALPHA_MAX);
+    n.inv_sigma = 1.0 / p.sigma;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int k = h.j + 6 * s;
+        n.a[s] = g(EPI_PRM_A + k); n.umin[s] = g(EPI_PRM_U_MIN + k); n.umax[s] = g(EPI_PRM_U_MAX + k);
+        n.ew[s] = p.epsilon * g(EPI_PRM_W_EFF + k);
+        // same products, same order as slope_term() / nlin_state_update(): constants of the chain, formed once
+        n.term[s] = p.gamma * p.dt * (p.sigma / 2.0) * n.a[s] * (n.umax[s] - n.umin[s]);
+    }
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) n.ga[k] = p.gamma * g(EPI_PRM_A + k);
+}
+// u(k, t) for my two NPIs (rows beyond n_npi read 0.0 through the descriptor's bounds check, see load_u)
+EPI_DEV void hx_load_u(const KArgs &a, int t, int su, int j, double (&u2)[2])
+{
+    const unsigned rowb = (unsigned)a.Su * 8u, voff = (unsigned)su * 8u + (unsigned)j * rowb;
+    const rsrc_t r = mk_rsrc(a.u + (size_t)t * a.n_npi * a.Su, (unsigned)a.n_npi * rowb);
+    u2[0] = bld(r, voff, 0u);
+    u2[1] = bld(r, voff, 6u * rowb);
+}
+// Addressing of the chain-blocked arrays (see Lay).  BLK > 0: the layout's lane_block is that compile-time constant (10 = one
+// block per wavefront, what the host chooses for this shape): the row pitch is 80 bytes, every row offset folds into the
+// instruction's 12-bit immediate and no scalar register holds one (the kernels run out of them otherwise and re-load their
+// arguments every day).  BLK = 0: any layout, row offsets in SGPRs.
+// Time slice t of an output array -- or, for an output the caller did not select (dst == NULL), an EMPTY descriptor: every
+// store through it is dropped by the bounds check, and no store sits behind a branch (the waits the compiler places for the
+// loads of a step count the stores issued since, which it can only do in straight-line code).
+template <int BLK>
+EPI_DEV rsrc_t hx_slice(const double *dst, int t, unsigned rows, const Lay &l, unsigned &voff, unsigned &rowb)
+{
+    const unsigned blk = BLK ? (unsigned)BLK : l.blk;
+    rowb = blk * 8u;
+    voff = (l.cb * rows * blk + l.cr) * 8u;
+    return mk_rsrc(dst ? dst + (size_t)t * rows * l.bp : nullptr, dst ? rows * l.bp * 8u : 0u);
+}
+template <int BLK> EPI_DEV void hx_st(rsrc_t r, unsigned vo, unsigned row, unsigned rowb, double v)
+{
+    if (BLK) hst(r, vo + row * ((unsigned)BLK * 8u), 0u, v); else hst(r, vo, row * rowb, v);
+}
+template <int BLK> EPI_DEV double hx_ld(rsrc_t r, unsigned vo, unsigned row, unsigned rowb)
+{
+    return BLK ? bld_s(r, vo + row * ((unsigned)BLK * 8u), 0u) : bld_s(r, vo, row * rowb);
+}
+template <int BLK>
+EPI_DEV void hx_store_u(double *__restrict__ dst, const KArgs &a, int t, const Lay &l, const HexLane &h, const double (&u2)[2])
+{
+    unsigned voff, rowb;
+    const rsrc_t r = hx_slice<BLK>(dst, t, (unsigned)a.n_npi, l, voff, rowb);
+    const unsigned vo = (voff + (unsigned)h.j * rowb) | h.dead;
+    // rows beyond n_npi lie beyond the slice (its last block's rows at the latest): dropped by the bounds check -- but a row
+    // k >= n_npi of an EARLIER block would land in the next block's rows, so those lanes are sent out of range as well
+    hx_st<BLK>(r, (h.j < a.n_npi) ? vo : 0xC0000000u, 0u, rowb, u2[0]);
+    hx_st<BLK>(r, (h.j + 6 < a.n_npi) ? vo : 0xC0000000u, 6u, rowb, u2[1]);
+}
+// bang-bang substitution of my NaN controls (OptControlled.m:49-58) and my slope-term contributions (:107-114)
+EPI_DEV void hx_resolve(const QPrm &p, const HexNpi &n, const ModelFlags &mf, double s6, const double (&u2)[2], double (&ur)[2],
+                        double (&tm)[2])
+{
+    const double gs6 = p.gamma * s6;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const double phi = n.ew[s] - gs6 * n.a[s];
+        const bool lo = mf.phi_ge ? (phi >= 0.0) : (phi > 0.0);
+        const bool fr = is_nan(u2[s]);
+        ur[s] = fr ? (lo ? n.umin[s] : n.umax[s]) : u2[s];
+        tm[s] = (fr && phi > -n.inv_sigma && phi < n.inv_sigma) ? n.term[s] : 0.0;
+    }
+}
+// my two values of a 12-vector to the chain's NPI row, then all twelve in NPI order
+EPI_DEV void hx_gather12(double *row_g, int j, const double (&v2)[2], double (&v)[kNpi])
+{
+    hx_fence();
+    row_g[j] = v2[0];
+    row_g[j + 6] = v2[1];
+    hx_fence();
+    const hx_d2 *q = (const hx_d2 *)row_g;
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+        const hx_d2 x = q[e];
+        v[2 * e] = x.x;
+        v[2 * e + 1] = x.y;
+    }
+}
+// my value of a 6-vector to the chain's vector row, then all six
+EPI_DEV void hx_gather6(double *row_g, int j, double mine, double (&v)[6])
+{
+    hx_fence();
+    row_g[j] = mine;
+    hx_fence();
+    const hx_d2 *q = (const hx_d2 *)row_g;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        const hx_d2 x = q[e];
+        v[2 * e] = x.x;
+        v[2 * e + 1] = x.y;
+    }
+}
+// slope_term(): a36 -= term(k) (+= for the time-flipped models), k ascending; 0.0 where a control does not qualify
+// (a36 never is -0.0, so adding or subtracting +0.0 leaves its bits)
+template <int FLIP>
+EPI_DEV double hx_slope(double *row_g, int j, const double (&u2)[2], const double (&tm2)[2])
+{
+    const bool any_free = is_nan(u2[0]) || is_nan(u2[1]);
+    if (__builtin_amdgcn_ballot_w64(any_free) == 0ull) return 0.0;      // historic days: no lane of the wave has a free control
+    double tm[kNpi];
+    hx_gather12(row_g, j, tm2, tm);
+    double a36 = 0.0;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) a36 = FLIP ? (a36 + tm[k]) : (a36 - tm[k]);
+    return a36;
+}
+// X(:, j) = A * v for the Jacobian's non-zero pattern (a_nz, ekf_sym.hpp): k ascending, structural zeros skipped
+EPI_DEV void hx_mul_A(const double (&A)[36], const double (&v)[6], double (&o)[6])
+{
+    constexpr int M = 6;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double acc = 0.0;
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            if (!a_nz<6>(i, k)) continue;
+            acc = first ? A[IXM(i, k)] * v[k] : fma(A[IXM(i, k)], v[k], acc);
+            first = false;
+        }
+        o[i] = acc;
+    }
+}
+
+// vector arrays (6 rows): lane j stores row j
+template <int BLK>
+EPI_DEV void hx_store_elem(double *__restrict__ dst, int t, const Lay &l, const HexLane &h, double v)
+{
+    unsigned voff, rowb;
+    const rsrc_t r = hx_slice<BLK>(dst, t, 6, l, voff, rowb);
+    hst(r, (voff + (unsigned)h.j * rowb) | h.dead, 0u, v);
+}
+// one-row arrays ([T][nblk * blk] doubles: innovations): the six lanes of a chain store the same word
+EPI_DEV void hx_store_scalar(double *__restrict__ dst, int t, const Lay &l, const HexLane &h, double v)
+{
+    hst(mk_rsrc(dst ? dst + (size_t)t * l.bp : nullptr, dst ? l.bp * 8u : 0u), (l.c * 8u) | h.dead, 0u, v);
+}
+EPI_DEV void hx_store_word(int32_t *__restrict__ dst, int t, const Lay &l, const HexLane &h, int32_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, mk_rsrc(dst ? dst + (size_t)t * l.bp : nullptr, dst ? l.bp * 4u : 0u), (l.c * 4u) | h.dead, 0u, 0);
+}
+template <int BLK>
+EPI_DEV void hx_load_vec(const double *__restrict__ src, int t, const Lay &l, double (&v)[6])
+{
+    unsigned voff, rowb;
+    const rsrc_t r = hx_slice<BLK>(src, t, 6, l, voff, rowb);
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = hx_ld<BLK>(r, voff, (unsigned)i, rowb);
+}
+// my element of a 6-row vector array
+template <int BLK>
+EPI_DEV double hx_load_elem(const double *__restrict__ src, int t, const Lay &l, int j)
+{
+    unsigned voff, rowb;
+    const rsrc_t r = hx_slice<BLK>(src, t, 6, l, voff, rowb);
+    return bld_s(r, voff + (unsigned)j * rowb, 0u);
+}
+// my column of a SYMMETRIC 6 x 6 array stored with all 36 rows (row e = i + 6 j): element (i, j) of my column goes to the
+// position of element (j, i) -- the same bits (the lane that owns column i stores the same value at (i, j)) -- so that one
+// store instruction covers rows 6 i + (0..5) of the wavefront's ten chains: 480 contiguous bytes when the layout block is
+// the wavefront's ten chains, instead of six 80-byte pieces 480 bytes apart (partial cache lines: measured 2.9 instead of
+// 1.2 ms for the forward kernel of the 9 375-chain shard)
+template <int BLK>
+EPI_DEV void hx_store_col(double *__restrict__ dst, int t, const Lay &l, const HexLane &h, const double (&v)[6])
+{
+    unsigned voff, rowb;
+    const rsrc_t r = hx_slice<BLK>(dst, t, 36, l, voff, rowb);
+    const unsigned vo = (voff + (unsigned)h.j * rowb) | h.dead;
+#pragma unroll
+    for (int i = 0; i < 6; i++) hx_st<BLK>(r, vo, (unsigned)(6 * i), rowb, v[i]);
+}
+// my column of a symmetric 6 x 6 array that hx_store_col wrote (all 36 rows): element (i, j) from the position of (j, i)
+template <int BLK>
+EPI_DEV void hx_load_col(const double *__restrict__ src, int t, const Lay &l, int j, double (&v)[6])
+{
+    unsigned voff, rowb;
+    const rsrc_t r = hx_slice<BLK>(src, t, 36, l, voff, rowb);
+    const unsigned vo = voff + (unsigned)j * rowb;
+#pragma unroll
+    for (int i = 0; i < 6; i++) v[i] = hx_ld<BLK>(r, vo, (unsigned)(6 * i), rowb);
+}
+
+// ---------------------------------------------------------------------------
+// forward pass: GenericExtendedKalmanFilter.m:98-169 (the monitor :172-179 is replayed by ekf_monitor)
+// ---------------------------------------------------------------------------
+struct HexFwdIn { double x, r, u[2]; };
+
+template <int FLIP, int BLK>
+__global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *__restrict__ dense_flag)
+{
+    constexpr int M = 6;
+    __shared__ __attribute__((aligned(16))) double tA[kHGp * kHT], tB[kHGp * kHT], tC[kHGp * kHT], tD[kHGp * kHT];
+    __shared__ __attribute__((aligned(16))) double vPC[kHGp * kHV], vK[kHGp * kHV], vD[kHGp * kHN], vTm[kHGp * kHN];
+#ifdef EPI_HEX_SOLO
+    asm volatile("" ::: "a60");                // probe: more than 256 registers, so that two of these waves never share a SIMD
+#endif
+    if (*dense_flag) return;
+    const HexLane h = hx_lane(a);
+    const int B = a.B, T = a.T, c = h.c, j = h.j;
+    const int sx = a.x_series ? a.x_series[c] : c;
+    const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    double *tAg = tA + kHT * h.g, *tBg = tB + kHT * h.g, *tCg = tC + kHT * h.g, *tDg = tD + kHT * h.g;
+    double *vPCg = vPC + kHV * h.g, *vKg = vK + kHV * h.g, *vDg = vD + kHN * h.g, *vTmg = vTm + kHN * h.g;
+
+    QPrm p;
+    HexNpi np;
+    hx_load_prm(p, np, a, B, h);
+    const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
+    const double gamma = a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c];
+
+    double sk_minus[M], Pc[M], Qv[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) sk_minus[i] = a.s_init[(size_t)i * B + c];
+    // Ps_init is bit-wise symmetric (ekf_precheck); the packed kernels read its upper triangle, so do we
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        Pc[i] = a.Ps_init[(size_t)IXM(lo, hi) * B + c];
+        Qv[i] = (i == j) ? a.Q[(size_t)IXM(j, j) * B + c] : 0.0;       // Q_w diagonal (ekf_precheck): row j of it
+    }
+    const double dk[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+
+    // time segments: see ekf_fwd_sym
+    const int k_begin = a.k_begin, k_end = (a.k_end > 0 && a.k_end < T) ? a.k_end : T;
+    if (k_begin > 0) {
+        hx_load_vec<BLK>(a.S_MINUS, tpos<FLIP>(k_begin, T), lay, sk_minus);
+        hx_load_col<BLK>(a.P_MINUS, tpos<FLIP>(k_begin, T), lay, j, Pc);
+    }
+    const unsigned voff_x = (unsigned)sx * 8u;
+    // the inputs of a day are requested one day ahead into one of two register sets used alternately (the loop body exists
+    // twice): nothing is copied at the end of a day, so no day ends by waiting for its own stores to drain
+    auto fetch = [&](int k, HexFwdIn &d) __attribute__((always_inline)) {
+        const int tn = tpos<FLIP>(k, T);
+        d.x = ldg(a.x + (size_t)tn * a.Sx, voff_x);
+        d.r = ldg(a.R_series + (size_t)k * a.Sx, voff_x);                 // R_v is not time-flipped (Backward*.m:27)
+        hx_load_u(a, tn, su, j, d.u);
+    };
+    auto day = [&](int k, const HexFwdIn &cur) __attribute__((always_inline)) {
+        const int t = tpos<FLIP>(k, T);
+        const double Rk = cur.r, xk = cur.x;
+        const double (&u_in)[2] = cur.u;
+
+        hx_store_elem<BLK>(a.S_MINUS, t, lay, h, hx_pick(sk_minus, j));          // :100-101
+        hx_store_col<BLK>(a.P_MINUS, t, lay, h, Pc);
+
+        double C[M];
+        obs_jacobian<M>(a.mf, sk_minus, C);                                 // :115, C(4:6) == 0
+        const double xk_minus = predict_obs<M>(a.mf, sk_minus, v_bar);      // :116-119
+
+        double innov, Kj, sk_plus[M], Ppc[M];
+        const bool valid = !is_nan(xk);                                     // :122 (per chain)
+        // EPI_HEX_BRANCHLESS: every chain goes through the update and one without an observation keeps its values by select
+        // (:130-135) -- the day is then ONE basic block, and the scheduler can fill the update's LDS round trips with the
+        // arithmetic of the state map and the Jacobian, which only need the gain
+        const bool upd = EPI_HEX_BRANCHLESS ? true : valid;
+        if (upd) {
+            innov = valid ? xk - xk_minus : 0.0;
+            // (P C')(j) = P(j, 0:2) C(0:2)' -- P(j, k) == P(k, j): my column.  (C P)(k) holds the same bits.
+            double PCj = Pc[0] * C[0];
+            PCj = fma(Pc[1], C[1], PCj);
+            PCj = fma(Pc[2], C[2], PCj);
+            double PC[M];
+            hx_gather6(vPCg, j, PCj, PC);
+            double CPCt = PC[0] * C[0];
+            CPCt = fma(PC[1], C[1], CPCt);
+            CPCt = fma(PC[2], C[2], CPCt);
+            const double den = CPCt + gamma * Rk;                           // :124 (D = 1, Hessian terms 0)
+            const double Kraw = PCj / den;
+            Kj = valid ? Kraw : 0.0;
+            double Kg[M], K[M];
+            hx_gather6(vKg, j, Kraw, Kg);
+#pragma unroll
+            for (int i = 0; i < M; i++) K[i] = Kg[i];
+#pragma unroll
+            for (int i = 0; i < M; i++) sk_plus[i] = valid ? sk_minus[i] + K[i] * innov : sk_minus[i];   // :129
+            // I - K C: its first three columns (C(4:6) = 0: the others are those of the identity)
+            double IK[M][3];
+#pragma unroll
+            for (int i = 0; i < M; i++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) IK[i][q] = ((i == q) ? 1.0 : 0.0) - K[i] * C[q];
+            // Joseph form :127.  T1 = (I - K C) P: my column
+            double T1c[M], T1r[M], Fr[M], Fc[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double acc = IK[i][0] * Pc[0];
+                acc = fma(IK[i][1], Pc[1], acc);
+                acc = fma(IK[i][2], Pc[2], acc);
+                T1c[i] = (i >= 3) ? acc + Pc[i] : acc;                      // + 1 * P(i, j) for i >= 3
+            }
+            hx_transpose(tAg, j, T1c, T1r);
+            // F = (T1 (I - K C)' + K R K') / gamma: my ROW, F(j, i) = sum_q T1(j, q) IK(i, q)
+            const double KjR = Kraw * Rk;
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double acc = T1r[0] * IK[i][0];
+                acc = fma(T1r[1], IK[i][1], acc);
+                acc = fma(T1r[2], IK[i][2], acc);
+                acc = (i >= 3) ? acc + T1r[i] : acc;                        // + T1(j, i) * 1 for i >= 3
+                Fr[i] = (acc + KjR * K[i]) / gamma;
+            }
+            hx_transpose(tBg, j, Fr, Fc);
+#pragma unroll
+            for (int i = 0; i < M; i++) Ppc[i] = valid ? (Fc[i] + Fr[i]) / 2.0 : Pc[i];     // :138
+        } else {                                                            // :130-135
+            innov = 0.0;
+            Kj = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) { sk_plus[i] = sk_minus[i]; Ppc[i] = Pc[i]; }
+        }
+        hx_store_elem<BLK>(a.K_GAIN, t, lay, h, Kj);
+        hx_store_scalar(a.innovations, t, lay, h, innov);
+        state_hard_margins<M>(p, sk_plus);                                  // :141
+        hx_store_elem<BLK>(a.S_PLUS, t, lay, h, hx_pick(sk_plus, j));            // :167-169
+        hx_store_col<BLK>(a.P_PLUS, t, lay, h, Ppc);
+
+        // s(k+1|k) = NlinStateUpdate(u, s+), A = StateJacobians(u, s+)  :155-157
+        double u_app[2], tm[2], d2[2], d[kNpi];
+        hx_resolve(p, np, a.mf, sk_plus[5], u_in, u_app, tm);
+        hx_store_u<BLK>(a.u_opt, a, t, lay, h, u_app);
+        d2[0] = np.umax[0] - u_app[0];
+        d2[1] = np.umax[1] - u_app[1];
+        hx_gather12(vDg, j, d2, d);
+        double dot = np.ga[0] * d[0];
+#pragma unroll
+        for (int q = 1; q < kNpi; q++) dot = fma(np.ga[q], d[q], dot);
+        double sk_next[M];
+        state_map<M, FLIP>(p, dot, sk_plus, sk_next);
+        {
+            // P(k+1|k) = sym(A P A' + Q)  :158-161: (A P)(:, j) mine, then row j of (A P) A', then the transposed half
+            double A[M * M], Tc[M], Tr[M], Gr[M], Gc[M];
+            jacobian_entries<M, FLIP>(p, sk_plus, hx_slope<FLIP>(vTmg, j, u_in, tm), A);
+            hx_mul_A(A, Ppc, Tc);
+            hx_transpose(tCg, j, Tc, Tr);
+            hx_mul_A(A, Tr, Gr);                                            // G(j, i) = sum_q (A P)(j, q) A(i, q)
+#pragma unroll
+            for (int i = 0; i < M; i++) Gr[i] = Gr[i] + Qv[i];
+            hx_transpose(tDg, j, Gr, Gc);
+#pragma unroll
+            for (int i = 0; i < M; i++) Pc[i] = (Gc[i] + Gr[i]) / 2.0;      // :161
+        }
+        state_hard_margins<M>(p, sk_next);                                  // :164
+#pragma unroll
+        for (int i = 0; i < M; i++) sk_minus[i] = sk_next[i];
+    };
+    {
+        HexFwdIn bufA, bufB;
+        int k = k_begin;
+        if (k < k_end) fetch(k, bufA);
+        // Everything loaded so far has landed before the loop is entered.  Otherwise the loop inherits the prologue's pending
+        // loads: the compiler's wait-count pass merges "requested just now, nothing issued since" (from here) with "requested a
+        // day ago, eighteen stores issued since" (from the back edge) into the stricter of the two, and EVERY day then begins
+        // by waiting until all but its own four new requests have drained -- i.e. for the previous day's stores.
+        __builtin_amdgcn_s_waitcnt(0);
+        while (k < k_end) {
+            if (k + 1 < T) fetch(k + 1, bufB);
+            day(k, bufA);
+            if (++k >= k_end) break;
+            if (k + 1 < T) fetch(k + 1, bufA);
+            day(k, bufB);
+            ++k;
+        }
+    }
+    if (k_end < T) {       // hand-over to the next time segment
+        hx_store_elem<BLK>(a.S_MINUS, tpos<FLIP>(k_end, T), lay, h, hx_pick(sk_minus, j));
+        hx_store_col<BLK>(a.P_MINUS, tpos<FLIP>(k_end, T), lay, h, Pc);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// backward recursion: GenericExtendedKalmanFilter.m:189-230 (X = pinv(P_MINUS) comes from eks_pinv, packed)
+// ---------------------------------------------------------------------------
+// EPI_HEX_SHARE_LOADS: what all six lanes of a chain need of the stored forward quantities (S+, S-, the 21 packed entries of X)
+// is loaded ONCE -- lane j its element of the vectors and the packed entries j, j + 6, j + 12, j + 18 of X -- and handed round
+// through LDS at the start of the step: 21 instead of 48 vector-memory instructions per step and lane (the six lanes'
+// replicated loads hit the same cache lines, but every one of them passes through the CU's one address unit, which four such
+// waves keep busy 57 % of the time)
+#ifndef EPI_HEX_SHARE_LOADS
+#define EPI_HEX_SHARE_LOADS 1
+#endif
+#if EPI_HEX_SHARE_LOADS
+struct HexBwdIn { double Spj, Sm1j, u[2], Ppc[6], Pm1c[6], Xp[4]; int rk; };
+#else
+struct HexBwdIn { double Sp[6], Sm1[6], u[2], Ppc[6], Pm1c[6], X[21]; int rk; };
+#endif
+
+template <int FLIP, int BLK>
+__global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *__restrict__ dense_flag)
+{
+    constexpr int M = 6;
+    __shared__ __attribute__((aligned(16))) double tJ[kHGp * kHT], tB[kHGp * kHT], tC[kHGp * kHT];
+    __shared__ __attribute__((aligned(16))) double vS[kHGp * kHV], vTm[kHGp * kHN];
+#if EPI_HEX_SHARE_LOADS
+    __shared__ __attribute__((aligned(16))) double vSp[kHGp * kHV], vSm[kHGp * kHV], tXs[kHGp * 24];
+#endif
+    if (*dense_flag) return;
+    const HexLane h = hx_lane(a);
+    const int B = a.B, T = a.T, c = h.c, j = h.j;
+    const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    double *tJg = tJ + kHT * h.g, *tBg = tB + kHT * h.g, *tCg = tC + kHT * h.g;
+    double *vSg = vS + kHV * h.g, *vTmg = vTm + kHN * h.g;
+#if EPI_HEX_SHARE_LOADS
+    double *vSpg = vSp + kHV * h.g, *vSmg = vSm + kHV * h.g, *tXg = tXs + 24 * h.g;
+#endif
+    QPrm p;
+    HexNpi np;
+    hx_load_prm(p, np, a, B, h);
+    // the clamp of MY state element (StateHardMargins: s, i, alpha; the costates are free)
+    const double my_lo = (j == 0) ? p.slo : (j == 1) ? p.ilo : p.alpha_min;
+    const double my_hi = (j == 2) ? p.alpha_max : 1.0;
+
+    // smoother steps of this launch: k = k_from down to k_to (see eks_bwd_sym); k_from = T - 2 starts from the terminal
+    // condition, a later launch resumes from the hand-over rows
+    const int k_from = a.bk_from, k_to = a.bk_to;
+    const size_t hp = (size_t)a.hand_pitch;
+    int st_guard = 0, st_cap = 0, min_rank = M;
+    double Ss[M], Psc[M];
+    const int tT = tpos<FLIP>(T - 1, T);
+    if (k_from < T - 2) {
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            Ss[i] = a.hand_s[(size_t)i * hp + c];
+            Psc[i] = a.hand_p[(size_t)IXM(i, j) * hp + c];
+        }
+        const int word = a.hand_i[c];
+        st_guard = word & 1; st_cap = (word >> 1) & 1; min_rank = word >> 8;
+    } else {
+        // terminal conditions GenericEKF.m:189-202 (Ps_final symmetric in values and NaN pattern: ekf_precheck)
+        hx_load_vec<BLK>(a.S_PLUS, tT, lay, Ss);
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const double f = a.s_final[(size_t)i * B + c];
+            if (!is_nan(f)) Ss[i] = f;
+        }
+        hx_load_col<BLK>(a.P_PLUS, tT, lay, j, Psc);
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const double f = a.Ps_final[(size_t)IXM(lo, hi) * B + c];
+            if (!is_nan(f)) Psc[i] = f;
+        }
+        hx_store_elem<BLK>(a.S_SMOOTH, tT, lay, h, hx_pick(Ss, j));
+        hx_store_col<BLK>(a.P_SMOOTH, tT, lay, h, Psc);
+        if (a.u_opt_smooth) {
+            const double z[2] = {0.0, 0.0};
+            hx_store_u<BLK>(a.u_opt_smooth, a, tT, lay, h, z);                   // column T is never written :95,204
+        }
+        hx_store_word(a.pinv_rank, tT, lay, h, -1);
+    }
+
+    // everything step k reads is requested one iteration ahead: the stored forward quantities come from HBM
+    auto fetch = [&](int k, HexBwdIn &d) __attribute__((always_inline)) {
+        const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
+#if EPI_HEX_SHARE_LOADS
+        d.Spj = hx_load_elem<BLK>(a.S_PLUS, t, lay, j);
+        hx_load_u(a, t, su, j, d.u);
+        d.rk = a.rankbuf[lay_scalar(t1, lay)];
+        hx_load_col<BLK>(a.P_PLUS, t, lay, j, d.Ppc);
+        {
+            unsigned voff, rowb;
+            const rsrc_t r = hx_slice<BLK>(a.X, t1, 21, lay, voff, rowb);  // (garbage where the :211 guard fired, rk < 0: unused)
+            const unsigned vo = voff + (unsigned)j * rowb;
+#pragma unroll
+            for (int m = 0; m < 3; m++) d.Xp[m] = hx_ld<BLK>(r, vo, (unsigned)(6 * m), rowb);
+            d.Xp[3] = hx_ld<BLK>(r, voff + (unsigned)(j < 3 ? j : 2) * rowb, 18u, rowb);     // packed entries 18..20 exist for j < 3
+        }
+        d.Sm1j = hx_load_elem<BLK>(a.S_MINUS, t1, lay, j);
+        hx_load_col<BLK>(a.P_MINUS, t1, lay, j, d.Pm1c);
+#else
+        hx_load_vec<BLK>(a.S_PLUS, t, lay, d.Sp);
+        hx_load_u(a, t, su, j, d.u);
+        d.rk = a.rankbuf[lay_scalar(t1, lay)];
+        hx_load_col<BLK>(a.P_PLUS, t, lay, j, d.Ppc);
+        {
+            unsigned voff, rowb;
+            const rsrc_t r = hx_slice<BLK>(a.X, t1, 21, lay, voff, rowb);  // (garbage where the :211 guard fired, rk < 0: unused)
+#pragma unroll
+            for (int e = 0; e < 21; e++) d.X[e] = hx_ld<BLK>(r, voff, (unsigned)e, rowb);
+        }
+        hx_load_vec<BLK>(a.S_MINUS, t1, lay, d.Sm1);
+        hx_load_col<BLK>(a.P_MINUS, t1, lay, j, d.Pm1c);
+#endif
+    };
+    auto step = [&](int k, const HexBwdIn &cur) __attribute__((always_inline)) {
+        const int t = tpos<FLIP>(k, T);
+#if EPI_HEX_SHARE_LOADS
+        double Sp[M], Sm1[M], X[24];
+        hx_gather6(vSpg, j, cur.Spj, Sp);
+        hx_gather6(vSmg, j, cur.Sm1j, Sm1);
+        {
+            tXg[j] = cur.Xp[0]; tXg[j + 6] = cur.Xp[1]; tXg[j + 12] = cur.Xp[2];
+            tXg[18 + j] = cur.Xp[3];                                       // lanes j >= 3 leave their duplicate in the padding entries 21..23
+            const hx_d2 *q = (const hx_d2 *)tXg;
+#pragma unroll
+            for (int e = 0; e < 11; e++) {
+                const hx_d2 x = q[e];
+                X[2 * e] = x.x;
+                X[2 * e + 1] = x.y;
+            }
+        }
+#else
+        const double (&Sp)[M] = cur.Sp;
+        const double (&Sm1)[M] = cur.Sm1;
+        const double (&X)[21] = cur.X;
+#endif
+
+        double A[M * M];
+        {
+            double ur_unused[2], tm[2];
+            hx_resolve(p, np, a.mf, Sp[5], cur.u, ur_unused, tm);
+            jacobian_entries<M, FLIP>(p, Sp, hx_slope<FLIP>(vTmg, j, cur.u, tm), A);   // :206
+        }
+        // J = (P+ A') X  :215.  Row j of P+ A' is A P+(:, j) (P+ symmetric bit for bit); row j of J needs all of X
+        double Jr[M];
+        int rank = -1;
+        const bool guard = cur.rk < 0;                                      // non-finite P_MINUS guard :211-213 (per chain)
+        {
+            double PAr[M];
+            hx_mul_A(A, cur.Ppc, PAr);                                      // (P+ A')(j, i) = sum_q P+(j, q) A(i, q)
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double acc = PAr[0] * X[sidx(0, i)];
+#pragma unroll
+                for (int q = 1; q < M; q++) acc = fma(PAr[q], X[sidx(q, i)], acc);
+                Jr[i] = guard ? 0.0 : acc;
+            }
+        }
+        if (guard) st_guard = 1;
+        else {
+            rank = cur.rk & 0xff;
+            st_cap |= (cur.rk >> 8) & 1;
+            min_rank = rank < min_rank ? rank : min_rank;
+        }
+        // S_SMOOTH(k) = clamp(s+ + J (s_s(k+1) - s-(k+1)))  :218-221: my element, then all six for the next step
+        double Sn[M];
+        {
+            double acc = Jr[0] * (Ss[0] - Sm1[0]);
+#pragma unroll
+            for (int q = 1; q < M; q++) acc = fma(Jr[q], Ss[q] - Sm1[q], acc);
+#if EPI_HEX_SHARE_LOADS
+            const double mine = cur.Spj + acc;
+#else
+            const double mine = hx_pick(Sp, j) + acc;
+#endif
+            const double clamped = fmin(my_hi, fmax(my_lo, mine));
+            hx_gather6(vSg, j, (j < 3) ? clamped : mine, Sn);
+        }
+        // P_SMOOTH(k) = sym(P+ - (J D) J'),  D = P_MINUS(k+1) - P_SMOOTH(k+1)   :223-226
+        {
+            double Jall[36], Dc[M], JDc[M], JDr[M], Fr[M], Fc[M];
+            hx_fence();
+            hx_put6(tJg + 6 * j, Jr);                                       // slot j = row j of J
+            hx_fence();
+            hx_get_all(tJg, Jall);                                          // Jall[6 i + q] = J(i, q)
+#pragma unroll
+            for (int i = 0; i < M; i++) Dc[i] = cur.Pm1c[i] - Psc[i];       // D(:, j)
+#pragma unroll
+            for (int i = 0; i < M; i++) {                                   // (J D)(:, j)
+                double acc = Jall[6 * i] * Dc[0];
+#pragma unroll
+                for (int q = 1; q < M; q++) acc = fma(Jall[6 * i + q], Dc[q], acc);
+                JDc[i] = acc;
+            }
+            hx_transpose(tBg, j, JDc, JDr);
+#pragma unroll
+            for (int i = 0; i < M; i++) {                                   // F(j, i) = P+(j, i) - sum_q (J D)(j, q) J(i, q)
+                double acc = JDr[0] * Jall[6 * i];
+#pragma unroll
+                for (int q = 1; q < M; q++) acc = fma(JDr[q], Jall[6 * i + q], acc);
+                Fr[i] = cur.Ppc[i] - acc;
+            }
+            hx_transpose(tCg, j, Fr, Fc);
+#pragma unroll
+            for (int i = 0; i < M; i++) Psc[i] = (Fc[i] + Fr[i]) / 2.0;     // :226
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) Ss[i] = Sn[i];
+        hx_store_word(a.pinv_rank, t, lay, h, (int32_t)rank);
+        hx_store_elem<BLK>(a.S_SMOOTH, t, lay, h, hx_pick(Ss, j));
+        hx_store_col<BLK>(a.P_SMOOTH, t, lay, h, Psc);
+        if (a.u_opt_smooth) {                                               // :229 -- only the control NlinStateUpdate returns is kept
+            double ur[2], tm_unused[2];
+            hx_resolve(p, np, a.mf, Ss[5], cur.u, ur, tm_unused);
+            hx_store_u<BLK>(a.u_opt_smooth, a, t, lay, h, ur);
+        }
+    };
+    // two input sets used alternately (the loop body exists twice): the prefetched values are consumed where they landed
+    {
+        HexBwdIn bufA, bufB;
+        int k = k_from;
+        if (k >= k_to) fetch(k, bufA);
+        __builtin_amdgcn_s_waitcnt(0);           // see ekf_fwd_hex: the loop must not inherit the prologue's pending loads
+        while (k >= k_to) {
+            if (k > k_to) fetch(k - 1, bufB);
+            step(k, bufA);
+            if (--k < k_to) break;
+            if (k > k_to) fetch(k - 1, bufA);
+            step(k, bufB);
+            --k;
+        }
+    }
+    if (!h.live) return;
+    if (k_to > 0) {        // hand-over to the launch that continues with step k_to - 1
+        a.hand_s[(size_t)j * hp + c] = hx_pick(Ss, j);
+        if (j == 0) a.hand_i[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+#pragma unroll
+        for (int i = 0; i < M; i++) a.hand_p[(size_t)IXM(i, j) * hp + c] = Psc[i];
+    } else if (a.status && j == 0) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+}

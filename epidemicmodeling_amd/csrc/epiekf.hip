@@ -67,6 +67,7 @@ struct KArgs {
     int lw;
     int quad;   // 6-state generic models: four lanes per chain (ekf_quad.hpp) instead of one
     int wave;   // 6-state generic models: one WAVEFRONT per chain (ekf_wave.hpp)
+    int hex;    // 6-state generic models: six lanes per chain, ten chains per wavefront (ekf_hex.hpp)
     // epi_batch_desc.storage = 1: the caller's outputs are fp32 arrays (same layouts, 4-byte elements); each selected
     // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
     // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
@@ -136,6 +137,12 @@ EPI_DEV double bld(rsrc_t r, unsigned voff, unsigned soff)
 EPI_DEV void bst(rsrc_t r, unsigned voff, unsigned soff, double v)
 {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, EPI_ST_AUX);
+}
+// non-temporal only: for layouts whose rows are not whole cache lines (the hex shape's ten-chain blocks, ekf_hex.hpp), where
+// writing through (`sc1`) turns every partial line into a memory transaction of its own
+EPI_DEV void bst_nt(rsrc_t r, unsigned voff, unsigned soff, double v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 2);
 }
 // a load of data that this launch reads exactly once (stored forward quantities, X)
 EPI_DEV double bld_s(rsrc_t r, unsigned voff, unsigned soff)
@@ -516,8 +523,13 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     int rank = sym_pinv_psd<M, WG>(Pu, Xu, &capped, &indef, plds + threadIdx.x);              // :215
     unsigned voff_x, rowb_x;
     const rsrc_t rx = lay_slice(a.X, t1, NSX, lay, voff_x, rowb_x);
+    if (a.hex) {       // 80-byte rows: see bst_nt (eks_pinv of the 9 375-chain shard 0.84 ms written through, 0.49 ms not)
 #pragma unroll
-    for (int i = 0; i < NSX; i++) bst(rx, voff_x, (unsigned)i * rowb_x, Xu[i]);
+        for (int i = 0; i < NSX; i++) bst_nt(rx, voff_x, (unsigned)i * rowb_x, Xu[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NSX; i++) bst(rx, voff_x, (unsigned)i * rowb_x, Xu[i]);
+    }
     *rword = rank | (capped ? 0x100 : 0);
     if (__builtin_amdgcn_ballot_w64(indef) != 0ull) {
         // Not positive semi-definite up to rounding (never the case for a covariance the filter produced from a positive
@@ -702,6 +714,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 #include "ekf_sym.hpp"
 #include "ekf_quad.hpp"
 #include "ekf_wave.hpp"
+#include "ekf_hex.hpp"
 
 // ---------------------------------------------------------------------------
 // forward simulators
@@ -1019,13 +1032,17 @@ static int shape_of(const epi_batch_desc *d, int dev)
         // 3 x 3 algebra the wave shape spreads over nine lanes is a small part of it.  Chosen up to 2 048 chains.
         const bool ok = monitor_hoisted(d);
         if (d->shape == EPI_SHAPE_WAVE) return ok ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
-        if (d->shape == EPI_SHAPE_LANE || d->shape == EPI_SHAPE_QUAD) return EPI_SHAPE_LANE;
+        if (d->shape == EPI_SHAPE_LANE || d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_HEX) return EPI_SHAPE_LANE;
         return (ok && d->B <= 2048) ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
     }
-    const bool wave_ok = monitor_hoisted(d);
+    const bool wave_ok = monitor_hoisted(d);       // the wave and hex shapes need the monitor as its own kernel and a fixed Q_w
     if (d->shape == EPI_SHAPE_WAVE) return wave_ok ? EPI_SHAPE_WAVE : EPI_SHAPE_QUAD;
+    if (d->shape == EPI_SHAPE_HEX) return wave_ok ? EPI_SHAPE_HEX : EPI_SHAPE_QUAD;
     if (d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_LANE) return d->shape;
     if (wave_ok && (long)d->B <= (long)simd_count(dev)) return EPI_SHAPE_WAVE;
+    // round 5: six lanes per chain, ten chains per wavefront (ekf_hex.hpp) while every such wavefront can have a SIMD of its own
+    // (B <= 10 240 on MI355X: the 9 375-chain shard of the headline sweep on one of 8 GPUs)
+    if (wave_ok && ((long)d->B + kHG - 1) / kHG <= (long)simd_count(dev)) return EPI_SHAPE_HEX;
     return ((long)d->B + kQC - 1) / kQC <= (long)simd_count(dev) ? EPI_SHAPE_QUAD : EPI_SHAPE_LANE;
 }
 
@@ -1147,6 +1164,14 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
             }
         }
         if constexpr (M == 6 && GENERIC) {
+            if (ka.hex && !done) {  // six lanes per chain, ten chains per wavefront (ekf_hex.hpp)
+                if (ka.blk == kHG) hipLaunchKernelGGL((ekf_fwd_hex<FLIP, kHG>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((ekf_fwd_hex<FLIP, 0>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                done = true;
+            }
+        }
+        if constexpr (M == 6 && GENERIC) {
             if (ka.quad && !done) {
                 // four lanes per chain, 16 chains per wavefront (ekf_quad.hpp): the specialisation for the layout and the
                 // window length this shape is meant for, or the general one
@@ -1236,6 +1261,13 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
             }
         }
         if constexpr (M == 6 && GENERIC) {
+            if (ka.hex && !done) {
+                if (ka.blk == kHG) hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((eks_bwd_hex<FLIP, 0>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                done = true;
+            }
+        }
+        if constexpr (M == 6 && GENERIC) {
             if (ka.quad && !done) {
                 const int qblocks = (ka.B + kQC - 1) / kQC;
                 if (ka.blk == kQC) hipLaunchKernelGGL((eks_bwd_quad<FLIP, kQC>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
@@ -1300,7 +1332,7 @@ static hipError_t rerun_nonfinite_dense(const KArgs &ka, const Launch &L, hipStr
     hipLaunchKernelGGL(mark_nonfinite, dim3((ka.B + 255) / 256), dim3(256), 0, st, (const int32_t *)ka.status, ka.only_buf, ka.B);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     KArgs kd = ka;
-    kd.only = ka.only_buf; kd.dense_flag = nullptr; kd.quad = 0; kd.mon_hoist = 0;
+    kd.only = ka.only_buf; kd.dense_flag = nullptr; kd.quad = 0; kd.hex = 0; kd.mon_hoist = 0;
     kd.k_begin = 0; kd.k_end = 0; kd.bk_from = ka.T - 2; kd.bk_to = 0;
     Launch Ld = L;
     Ld.hint = 2; Ld.tail = nullptr;
@@ -1389,7 +1421,7 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         ne++;
         return ee;
     };
-    const long fwd_waves = ka.quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
+    const long fwd_waves = ka.hex ? ((long)ka.B + kHG - 1) / kHG : ka.quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
     // (one wavefront per chain: the pinv grid of so few chains takes ~30 us, nothing to pipeline -- unless asked for)
     const bool tp = ka.mon_hoist && !ka.stor && T >= 128 && L.time_pipe >= 0 &&
                     (L.time_pipe == 1 || (!ka.wave && fwd_waves * 4 <= (long)simd_count(L.dev) * 3));
@@ -1491,7 +1523,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->path_hint < 0 || d->path_hint > 2) { set_err(err, "path_hint must be 0, 1 or 2"); return EPI_ERR_BAD_ARG; }
     if (d->time_pipe < -1 || d->time_pipe > 1) { set_err(err, "time_pipe must be -1 (off), 0 (auto) or 1 (on)"); return EPI_ERR_BAD_ARG; }
     if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
-    if (d->shape < 0 || d->shape > 3) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain), 2 (four lanes per chain) or 3 (one wavefront per chain)"); return EPI_ERR_BAD_ARG; }
+    if (d->shape < 0 || d->shape > 4) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain), 2 (four lanes per chain), 3 (one wavefront per chain) or 4 (six lanes per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
     if (d->exact_nonfinite < 0 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 or 1"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
@@ -1514,7 +1546,7 @@ int epi_ekf_preferred_lane_block(const epi_batch_desc *d)
     const ModelInfo &mi = MODEL_TABLE[d->model];
     const int dev = current_device();
     const int sh = shape_of(d, dev);
-    const int lw = sh == EPI_SHAPE_WAVE ? 1 : (sh == EPI_SHAPE_QUAD ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2, dev));
+    const int lw = sh == EPI_SHAPE_WAVE ? 1 : (sh == EPI_SHAPE_HEX ? kHG : (sh == EPI_SHAPE_QUAD ? kQC : balanced_lanes(d->B, mi.m == 6 ? 1 : 2, dev)));
     return lw < d->B ? lw : d->B;
 }
 
@@ -1554,6 +1586,7 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     const int dev = current_device();
     ka.quad = shape_of(d, dev) == EPI_SHAPE_QUAD ? 1 : 0;
     ka.wave = shape_of(d, dev) == EPI_SHAPE_WAVE ? 1 : 0;
+    ka.hex = shape_of(d, dev) == EPI_SHAPE_HEX ? 1 : 0;
     ka.stor = f32 ? 1 : 0;
     ka.bk_from = d->T - 2; ka.bk_to = 0;
     ka.c0 = 0; ka.cn = d->B;

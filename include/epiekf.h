@@ -151,7 +151,12 @@ typedef struct epi_batch_desc {
                              3 = one WAVEFRONT per chain (ekf_fwd_wave / eks_bwd_wave: lane e = i + 6 j owns element (i, j) of
                              every 6 x 6 matrix, operands exchanged through LDS; the shortest per-day latency, for batches of
                              at most one chain per SIMD -- the reference's own one-call-per-cost-weight loop; needs R_v as a
-                             per-day series, else falls back to 2).  Auto: 3 up to 1024 chains, 2 up to 16 384, then 1.
+                             per-day series, else falls back to 2), 4 = SIX lanes per chain, ten chains per wavefront
+                             (ekf_fwd_hex / eks_bwd_hex: lane j of a chain owns column j of every 6 x 6 matrix; the stored
+                             covariances are symmetric bit for bit, so every product needs one transpose through LDS and the
+                             Jacobian's zeros are skipped -- about half the quad shape's instructions per day; same conditions
+                             as 3).  Auto: 3 up to 1024 chains, 4 up to 10 240 (the 9 375-chain shard of the headline sweep on
+                             one of 8 GPUs), 2 up to 16 384, then 1.
                              The 3-state generic models know 1 and 3 (there: SEVEN chains per wavefront, nine lanes each,
                              ekf_fwd_wave3 / eks_bwd_wave3; auto: 3 up to 2 048 chains).  Results are bit-identical in all
                              shapes.  Ignored by the NewCase models. */
@@ -172,7 +177,7 @@ typedef struct epi_batch_desc {
                              the flag.  0: as the kernels leave them (`status` still tells which chains). */
 } epi_batch_desc;
 
-typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3 } epi_shape;
+typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3, EPI_SHAPE_HEX = 4 } epi_shape;
 
 typedef struct epi_inputs {
     const int32_t *x_series; /* [B] or NULL */

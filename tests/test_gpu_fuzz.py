@@ -80,7 +80,7 @@ def build(draw):
     lane_block = draw(st.sampled_from([0, 0, 3, 8, 16, 32, "auto"]))
     time_pipe = draw(st.sampled_from([0, 0, 1, -1]))
     # lane mapping of the 6-state generic models: one lane per chain, four lanes per chain, or the library's own choice
-    shape = draw(st.sampled_from(["lane", "quad", "wave", "wave", "auto"]))
+    shape = draw(st.sampled_from(["lane", "quad", "wave", "hex", "hex", "auto"]))
     return w, lane_block, time_pipe, kind, shape
 
 
@@ -124,7 +124,7 @@ def test_random_sweeps_through_the_one_call_entry(gpu_device, data):
         w.Q = w.Q.copy(); w.Q[1] = 1e-13                       # non-diagonal Q_w: dense kernels, tail after the smoother
     outputs = draw(st.sampled_from([None, ["u_opt_smooth"], ["u_opt_smooth", "S_SMOOTH"], ["u_opt_smooth", "P_SMOOTH", "rho", "S_PLUS"]]))
     lane_block = draw(st.sampled_from([0, 0, 8, 16, 40, "auto"]))
-    shape = draw(st.sampled_from(["lane", "quad", "wave", "auto"]))
+    shape = draw(st.sampled_from(["lane", "quad", "wave", "hex", "auto"]))
     time_pipe = draw(st.sampled_from([0, 1, -1]))
     with_front = draw(st.booleans())
     n, B = w.n_npi, w.B
