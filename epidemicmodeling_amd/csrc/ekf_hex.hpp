@@ -352,6 +352,9 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *_
 #ifdef EPI_HEX_SOLO
     asm volatile("" ::: "a60");                // probe: more than 256 registers, so that two of these waves never share a SIMD
 #endif
+#ifdef EPI_HEX_PRIO
+    __builtin_amdgcn_s_setprio(3);             // probe: the latency-bound forward waves ahead of co-resident pinv waves
+#endif
     if (*dense_flag) return;
     const HexLane h = hx_lane(a);
     const int B = a.B, T = a.T, c = h.c, j = h.j;

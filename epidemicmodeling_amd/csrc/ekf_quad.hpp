@@ -258,6 +258,60 @@ __global__ __launch_bounds__(kWave) void ekf_monitor(const KArgs a, const int *_
     }
 }
 
+// The same monitor with NO sequential scan (round 5): one lane per (chain, block of D days), everything in registers.
+// rho(k) is a function of the 2L - 1 innovations up to day k: the lane loads the D + 2L - 2 innovations its D days see, forms
+// the D + L - 1 window means and normalised squares they need (each window summed newest -> oldest, exactly the ring's order,
+// with the zeros the rings hold before step 0), then the D window sums of those.  L - 1 of every D + L - 1 means are formed
+// again by the neighbouring lane -- ~210 instructions per (chain, day) instead of ~100 -- but nothing waits on anything: the
+// scan kernel's lanes walk ~100 dependent steps each (0.24 ms alone at 9 375 chains, 0.7 ms beside the pinv grid, and the
+// smoother's first launch beside it runs 0.1 ms longer); this grid is done in ~0.05 ms.  L = 21 (what every caller passes).
+template <int FLIP, int LC, int D>
+__global__ __launch_bounds__(kWave) void ekf_monitor_par(const KArgs a, const int *__restrict__ dense_flag)
+{
+    constexpr int L = LC, NI = D + 2 * L - 2, NM = D + L - 1;
+    if (*dense_flag) return;          // the dense kernels keep the monitor inline
+    const int c = a.c0 + blockIdx.x * kWave + (int)threadIdx.x;
+    if (c >= a.c0 + a.cn) return;
+    const int T = a.T;
+    const int k0 = (int)blockIdx.y * D;
+    if (k0 >= T) return;
+    const int sx = a.x_series ? a.x_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    double in[NI], ccn[NM];
+#pragma unroll
+    for (int q = 0; q < NI; q++) {
+        const int kq = k0 - (2 * L - 2) + q;
+        in[q] = (kq >= 0 && kq < T) ? a.innovations[lay_scalar(tpos<FLIP>(kq, T), lay)] : 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        const int kp = k0 - (L - 1) + m;                 // the day whose normalised square this is
+        const int q = m + L - 1;                         // its innovation
+        double sum = in[q];
+#pragma unroll
+        for (int jj = 1; jj < L; jj++) sum = sum + in[q - jj];
+        const int cnt = (kp + 1 < L) ? (kp + 1) : L;
+        const bool live = kp >= 0 && kp < T;
+        const double Rk = live ? a.R_series[(size_t)kp * a.Sx + sx] : 1.0;     // R_v is not time-flipped (Backward*.m:27)
+        const double mu = sum / (double)(live ? cnt : 1);
+        const double cc = (in[q] - mu) * (in[q] - mu);
+        ccn[m] = live ? cc / (Rk + kEps) : 0.0;          // before step 0 the ring holds zeros
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const int k = k0 + d;
+        if (k >= T) break;
+        const int m = d + L - 1;
+        double sumN = ccn[m];
+#pragma unroll
+        for (int jj = 1; jj < L; jj++) sumN = sumN + ccn[m - jj];
+        const int cnt = (k + 1 < L) ? (k + 1) : L;
+        const double rho = sumN / (double)cnt;
+        if (a.rho) a.rho[lay_scalar(k, lay)] = rho;                          // filter-step order also when FLIP
+        if (a.f.rho) a.f.rho[lay_scalar(k, lay)] = (float)rho;
+    }
+}
+
 // rows of the Jacobian a lane multiplies with: its block row's (bi) and its block column's (bj)
 EPI_DEV void qrows(const double (&A)[36], bool hi, double (&R)[3][6])
 {

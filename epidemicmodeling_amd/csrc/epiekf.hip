@@ -1123,8 +1123,19 @@ template <int FLIP>
 static hipError_t launch_monitor(const KArgs &ka, int dev, hipStream_t st)
 {
     if (!ka.mon_hoist || !(ka.rho || ka.f.rho)) return hipSuccess;
+#ifdef EPI_PROBE_NO_MONITOR        // timing probe: rho is not computed
+    return hipSuccess;
+#endif
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
     const int mb = (ka.B + kWave - 1) / kWave;
+#ifndef EPI_MONITOR_PAR_MAX_WAVES
+#define EPI_MONITOR_PAR_MAX_WAVES 2       // use the scan-free grid (ekf_monitor_par) while the batch has at most that many waves per SIMD
+#endif
+    if (ka.L == 21 && (long)mb <= (long)EPI_MONITOR_PAR_MAX_WAVES * simd_count(dev)) {
+        constexpr int D = 8;
+        hipLaunchKernelGGL((ekf_monitor_par<FLIP, 21, D>), dim3(mb, (ka.T + D - 1) / D), dim3(kWave), 0, st, ka, ka.dense_flag);
+        return hipGetLastError();
+    }
     // time segments (each pays a 2L-2-step warm-up): enough of them that the grid gives every SIMD about eight of these
     // light waves (a lane's 100-step scan is latency-bound: 0.70 ms with two segments, 0.25 ms with eight at 75 000 chains),
     // none shorter than ~64 steps
