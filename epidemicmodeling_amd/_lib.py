@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # EPIEKF_LIB: load another build of the same ABI instead (A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 
-ABI_VERSION = 4      # EPIEKF_ABI_VERSION of include/epiekf.h
+ABI_VERSION = 5      # EPIEKF_ABI_VERSION of include/epiekf.h
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_ekf_run_host_multi", "epi_host_pool_release", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",

@@ -62,7 +62,7 @@ class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
     def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, time_pipe=0, precheck=True, lane_block=0, shape=0,
-                 storage="f64", exact_nonfinite=False, slab=None):
+                 storage="f64", exact_nonfinite=None, slab=None):
         """time_pipe: epi_batch_desc.time_pipe (0 = the library decides whether a full call runs its forward kernel in time
         segments with the pinv grid of each segment beside the next, 1 = on, -1 = off).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
@@ -83,7 +83,8 @@ class EkfRunner:
         self.desc.storage = {"f64": 0, "f32": 1}[storage]
         # epi_batch_desc.exact_nonfinite: chains whose covariance overflows are run again by the dense kernels, in place
         # (their Inf / NaN pattern is then the dense evaluation's, i.e. the reference's)
-        self.desc.exact_nonfinite = int(bool(exact_nonfinite))
+        # None = the library's default (on whenever the smoother runs), True = always, False = off
+        self.desc.exact_nonfinite = 0 if exact_nonfinite is None else (1 if exact_nonfinite else -1)
         odt = torch.float32 if storage == "f32" else torch.float64
         if lane_block == "auto":       # one block per wavefront of the launch
             lane_block = int(_lib.lib().epi_ekf_preferred_lane_block(C.byref(self.desc)))
@@ -103,11 +104,33 @@ class EkfRunner:
             else:
                 shapes[n] = (dw.T, self.nblk * self.blk) if rows == 0 else (dw.T, self.nblk, rows, self.blk)
         self.ws_bytes = int(h.epi_ekf_workspace_bytes(C.byref(self.desc)))
+        self._shapes, self._odt, self._slab_opt = shapes, odt, slab
+        self._allocate()
+        self.pinv_rank = torch.empty((dw.T, self.nblk * self.blk), dtype=torch.int32, device=dev) if extras else None
+        self.status = torch.zeros((dw.B,), dtype=torch.int32, device=dev) if extras else None
+        self.ins = dw.inputs_struct()
+        self.desc.time_pipe = int(time_pipe)
+        self._sweep = None
+        if precheck:
+            ok = C.c_int(0)
+            st = torch.cuda.current_stream(dev)
+            rc = h.epi_ekf_precheck_device(C.byref(self.desc), C.byref(self.ins), C.c_void_p(st.cuda_stream),
+                                           C.byref(ok), self.err)
+            _lib.check(rc, self.err)
+            self.desc.path_hint = 1 if ok.value else 2
+        self._bind()
+
+    def _allocate(self):
+        """The outputs and the workspace (fresh device memory; `out` / `ws` are replaced)."""
+        dw, names, shapes, odt, slab = self.dw, self.names, self._shapes, self._odt, self._slab_opt
+        dev = dw.device
+        self.out = {}
         ws_elems = (max(self.ws_bytes, 8) + 7) // 8
         if slab is None:
             for n in names:
                 self.out[n] = torch.empty(shapes[n], dtype=odt, device=dev)
             self.ws = torch.empty(ws_elems, dtype=torch.float64, device=dev)
+            self._slab = None
         else:
             # ONE device allocation for every output and the workspace (slab = {"align": bytes, "stagger": bytes}): array i
             # starts at a multiple of `align` plus i * `stagger` -- the arrays' relative placement is then the caller's choice
@@ -126,23 +149,52 @@ class EkfRunner:
                 self.out[n] = self._slab[o:o + nb].view(odt).view(shapes[n])
             o, nb = offs["__ws__"]
             self.ws = self._slab[o:o + nb].view(torch.float64)
-        self.pinv_rank = torch.empty((dw.T, self.nblk * self.blk), dtype=torch.int32, device=dev) if extras else None
-        self.status = torch.zeros((dw.B,), dtype=torch.int32, device=dev) if extras else None
-        self.ins = dw.inputs_struct()
-        self.desc.time_pipe = int(time_pipe)
-        self._sweep = None
-        if precheck:
-            ok = C.c_int(0)
-            st = torch.cuda.current_stream(dev)
-            rc = h.epi_ekf_precheck_device(C.byref(self.desc), C.byref(self.ins), C.c_void_p(st.cuda_stream),
-                                           C.byref(ok), self.err)
-            _lib.check(rc, self.err)
-            self.desc.path_hint = 1 if ok.value else 2
+
+    def _bind(self):
         self.outs = _lib.Outputs()
         for n in OUT_NAMES:
             setattr(self.outs, n, _ptr(self.out.get(n)))
         self.outs.pinv_rank = _ptr(self.pinv_rank)
         self.outs.status = _ptr(self.status)
+
+    def stage_ms(self, passes=2):
+        """(forward, pinv, smoother) milliseconds of a pass enqueued stage by stage (HIP events on the current stream), the
+        mean over `passes` after one untimed pass."""
+        dev = self.dw.device
+        self.run(phase=1); self.run(phase=3); self.run(phase=4)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(passes)]
+        for e in ev:
+            e[0].record(); self.run(phase=1); e[1].record(); self.run(phase=3); e[2].record(); self.run(phase=4); e[3].record()
+        torch.cuda.synchronize(dev)
+        return tuple(float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i in range(3))
+
+    def tune_placement(self, tries=3):
+        """Where the allocator puts the ~14 arrays a pass streams concurrently changes the forward kernel's and the smoother's
+        time by up to 15 % (they meet in the physically indexed L2's sets and banks or they do not: DESIGN.md 5, "where the
+        arrays lie"), it is a property of the ALLOCATION -- the same arrays give the same time run after run -- and the caller
+        cannot see it.  So: time a staged pass on this allocation, allocate the outputs and the workspace again (`tries` - 1
+        times, each while the earlier ones are still held, so that other memory is handed out), keep the fastest and free the
+        rest.  One-time set-up cost: a few passes and, transiently, `tries` x the outputs' memory (skipped when that does not
+        fit).  Returns {"tries": [...ms per try...], "chosen": i}."""
+        dev = self.dw.device
+        held, log = [], []
+        need = sum(t.numel() * t.element_size() for t in self.out.values()) + self.ws.numel() * 8
+        for i in range(max(1, int(tries))):
+            if i > 0:
+                free, _ = torch.cuda.mem_get_info(dev)
+                if free < need * 1.05:
+                    break
+                self._allocate()
+                self._bind()
+            f, p, b = self.stage_ms()
+            log.append({"fwd_ms": f, "pinv_ms": p, "bwd_ms": b, "sum_ms": f + p + b})
+            held.append((self.out, self.ws, self._slab))
+        best = int(np.argmin([x["sum_ms"] for x in log]))
+        self.out, self.ws, self._slab = held[best]
+        self._bind()
+        del held
+        torch.cuda.empty_cache()
+        return {"tries": log, "chosen": best}
 
     def run(self, stream=None, phase: int = 0):
         """Enqueue forward + backward kernels on `stream` (default: torch's current stream).
@@ -178,6 +230,7 @@ class EkfRunner:
                 res["on_front"] = torch.empty((int(n_regions), P), dtype=torch.int32, device=dev)
                 res["i_opt"] = torch.empty((int(n_regions),), dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream(dev) if stream is None else stream
+        self.desc.phase = 0
         rc = _lib.lib().epi_sweep_run_device(C.byref(self.desc), C.byref(self.ins), C.byref(self.outs), _ptr(self.ws), self.ws_bytes,
                                              C.byref(sd), _ptr(sp), _ptr(J0_prefix), _ptr(J1_prefix), _ptr(res["J0"]), _ptr(res["J1"]),
                                              _ptr(res.get("on_front")) if n_regions else None,
@@ -210,7 +263,7 @@ class EkfRunner:
 
 
 def run_workload(w, outputs=None, device="cuda:0", extras=True, time_pipe=0, precheck=True, lane_block=0, shape=0, storage="f64",
-                 exact_nonfinite=False):
+                 exact_nonfinite=None):
     """Convenience: upload `w`, run once, return dict name -> numpy array [T, rows, B] (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
     r = EkfRunner(dw, outputs, extras=extras, time_pipe=time_pipe, precheck=precheck, lane_block=lane_block, shape=shape, storage=storage,

@@ -120,6 +120,9 @@ __global__ __launch_bounds__(256) void ekf_precheck(const KArgs a, int *__restri
 #ifndef EPI_BWD_LB
 #define EPI_BWD_LB kWave
 #endif
+#ifndef EPI_FWD3_WAVES
+#define EPI_FWD3_WAVES 3          // waves per SIMD the 3-state forward variant with LDS-resident a / u_max is compiled for
+#endif
 // Two knobs of the packed smoother, settled by A/B runs on the headline sweep (profiles/ab_phase.py 4, medians):
 //   EPI_BWD_PREFETCH  what is requested one step ahead (bit 0: state, controls, rank word; bit 1: P_PLUS; bit 2: X)
 //   EPI_BWD_RECOMPUTE 1: s(k+1|k), P(k+1|k) are recomputed from the stored s(k|k), P(k|k), u with the forward kernel's
@@ -138,6 +141,7 @@ constexpr int kPipeLanes = 40;   // lanes per workgroup of the LP = 1 forward va
 // where the forward kernel keeps the model constants (see ekf_fwd_sym)
 template <int LP> struct PrmSelect { typedef ChainPrm type; };
 template <> struct PrmSelect<1> { typedef LitePrm<VecLdsS> type; };
+template <> struct PrmSelect<2> { typedef LitePrm<VecLds2> type; };     // 3-state: a, u_max in LDS (64-lane stride), see ekf_fwd_sym
 template <int M>
 EPI_DEV void init_prm(ChainPrm &p, const KArgs &a, int B, int c, double *, int) { load_prm<M>(p, a.prm, B, c, a.mf.lo_is_zero); }
 template <int M>
@@ -151,6 +155,18 @@ EPI_DEV void init_prm(LitePrm<VecLdsS> &p, const KArgs &a, int B, int c, double 
         col[(1 * kNpi + k) * stride] = a.prm[(size_t)(EPI_PRM_U_MIN + k) * B + c];
         col[(2 * kNpi + k) * stride] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
         col[(3 * kNpi + k) * stride] = a.prm[(size_t)(EPI_PRM_W_EFF + k) * B + c];
+    }
+}
+
+template <int M>
+EPI_DEV void init_prm(LitePrm<VecLds2> &p, const KArgs &a, int B, int c, double *col, int)
+{
+    load_lite(p, a.prm, B, c, a.mf.lo_is_zero);
+    p.v.base = col;
+#pragma unroll
+    for (int k = 0; k < kNpi; k++) {
+        col[(0 * kNpi + k) * kWave] = a.prm[(size_t)(EPI_PRM_A + k) * B + c];
+        col[(1 * kNpi + k) * kWave] = a.prm[(size_t)(EPI_PRM_U_MAX + k) * B + c];
     }
 }
 
@@ -205,8 +221,15 @@ EPI_DEV void predict_cov_sym(const double (&A)[M * M], const double (&Pp)[M * (M
 //         (epi_batch_desc.chunks = -2) runs one half's eks_pinv grid in the issue slots the other half's forward waves
 //         leave idle.
 // MON = 0: the innovation monitor runs as a kernel of its own (ekf_monitor, ekf_quad.hpp: r_mode 1 only) -- no windows here
-template <int M, int FLIP, int LP, int STOR = 0, int MON = 1>
-__global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const int *__restrict__ dense_flag)
+// USD = 1 ("u same day", round 5): the twelve controls of a day are requested at the top of THAT day, still ahead of its stores
+//         -- they are first used ~700 instructions later (NlinStateUpdate, after the Joseph form) -- instead of a day ahead: 24
+//         registers no longer live across the whole loop, and <6, FLIP, 1, 0, 0, 1> needs 255 registers and no accumulation
+//         registers at all: TWO waves per SIMD (the verdict r04's item 2; 255 + 20 without).  Used where the kernel is bound by
+//         the per-day latency of a lone wave, i.e. when the forward quantities are workspace (reduced outputs): forward stage
+//         4.23 -> 3.86 ms; with all outputs, where it is bound by its 104 store rows per day, two resident waves per SIMD write
+//         WORSE (5.7 -> 6.0 ms), and the 3-state kernels use the controls too early in the day (config 5: 8.7 -> 9.4 ms).
+template <int M, int FLIP, int LP, int STOR = 0, int MON = 1, int USD = 0>
+__global__ __launch_bounds__(EPI_FWD_LB, (M == 3 && LP == 2) ? EPI_FWD3_WAVES : 1) void ekf_fwd_sym(const KArgs a, const int *__restrict__ dense_flag)
 {
     extern __shared__ double lds[];   // three sliding windows [3][L][stride], one column per lane (+ [48][stride], LP)
     if (*dense_flag) return;          // ekf_fwd (dense) runs instead
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     const int su = a.u_series ? a.u_series[c] : c;
     const Lay lay = make_lay(a, c);
 
-    constexpr int stride = LP ? kPipeLanes : kWave;   // compile-time: LDS offsets stay immediates
+    constexpr int stride = (LP == 1) ? kPipeLanes : kWave;   // compile-time: LDS offsets stay immediates
     typename PrmSelect<LP>::type p;
     init_prm<M>(p, a, B, c, lds + (size_t)(MON ? 3 * L : 0) * stride + lane, stride);
     const double v_bar = a.prm[(size_t)EPI_PRM_V_BAR * B + c];
@@ -260,20 +283,45 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
     double x_nxt = ldg(a.x + (size_t)tpos<FLIP>(k_begin, T) * a.Sx, voff_x);
     double r_nxt = fixed_R ? 0.0 : ldg(a.R_series + (size_t)k_begin * a.Sx, voff_x);
     double u_nxt[kNpi];
-    load_u(a, tpos<FLIP>(k_begin, T), su, u_nxt);
+    if (!USD) load_u(a, tpos<FLIP>(k_begin, T), su, u_nxt);
+    // LP = 2 (3-state): NlinStateUpdate returns u as it came (SIAlphaModelEKF.m:39) and its fma chain (gamma a')(u_max - u)
+    // does not depend on the state, so a day's controls are consumed when they ARRIVE -- at the end of the day before: u_opt
+    // stored, the dot product formed -- and only that scalar crosses into the day (one control vector live instead of two)
+    double dot_cur = 0.0;
+    auto consume_u = [&](int tt, bool store) __attribute__((always_inline)) {
+        if (store) {
+            store_u(a.u_opt, a, tt, lay, u_nxt);
+            if (STOR) store_rows_f32<kNpi>(a.f.u_opt, tt, (unsigned)a.n_npi, lay, u_nxt);
+        }
+        dot_cur = (p.gamma * p.A(0)) * (p.Umax(0) - u_nxt[0]);
+#pragma unroll
+        for (int q = 1; q < kNpi; q++) dot_cur = fma(p.gamma * p.A(q), p.Umax(q) - u_nxt[q], dot_cur);
+    };
+    if (LP == 2 && k_begin < k_end) consume_u(tpos<FLIP>(k_begin, T), true);
 
     for (int k = k_begin; k < k_end; k++) {
         const int t = tpos<FLIP>(k, T);
         const double Rk = fixed_R ? R_next : r_nxt;
         const double xk = x_nxt;
+        if constexpr (LP == 2) {
+            // the LDS column's address is made opaque once a day: hipcc otherwise hoists the 24 reads of a(k), u_max(k) out of
+            // the loop -- back into the 48 registers the LDS copy is there to free
+            const double *q = p.v.base;
+            asm volatile("" : "+v"(q));
+            p.v.base = q;
+        }
         double u_in[kNpi];
+        const double dot_day = dot_cur;
+        if (USD) load_u(a, t, su, u_in);
+        else if (LP != 2) {
 #pragma unroll
-        for (int q = 0; q < kNpi; q++) u_in[q] = u_nxt[q];
+            for (int q = 0; q < kNpi; q++) u_in[q] = u_nxt[q];
+        }
         if (k + 1 < T) {
             const int tn = tpos<FLIP>(k + 1, T);
             x_nxt = ldg(a.x + (size_t)tn * a.Sx, voff_x);
             if (!fixed_R) r_nxt = ldg(a.R_series + (size_t)(k + 1) * a.Sx, voff_x);
-            load_u(a, tn, su, u_nxt);
+            if (!USD) load_u(a, tn, su, u_nxt);
         }
 
         store_vec<M>(a.S_MINUS, t, lay, sk_minus);
@@ -348,13 +396,19 @@ __global__ __launch_bounds__(EPI_FWD_LB) void ekf_fwd_sym(const KArgs a, const i
         }
         state_hard_margins<M>(p, sk_plus);
 
-        double u_app[kNpi];
+        if constexpr (LP == 2) {
+            state_map<M, FLIP>(p, dot_day, sk_plus, sk_minus);
+            double A[M * M];
+            jacobian_entries<M, FLIP>(p, sk_plus, 0.0, A);         // no slope term for three states
+            predict_cov_sym<M>(A, Pp, Qd, Pm);
+            if (k + 1 < T) consume_u(tpos<FLIP>(k + 1, T), k + 1 < k_end);   // tomorrow's controls have arrived
+        } else {
+            double u_app[kNpi];
 #pragma unroll
-        for (int q = 0; q < kNpi; q++) u_app[q] = u_in[q];
-        nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
-        store_u(a.u_opt, a, t, lay, u_app);
-        if (STOR) store_rows_f32<kNpi>(a.f.u_opt, t, (unsigned)a.n_npi, lay, u_app);
-        {
+            for (int q = 0; q < kNpi; q++) u_app[q] = u_in[q];
+            nlin_state_update<M, FLIP>(p, a.mf, u_app, sk_plus, sk_minus);
+            store_u(a.u_opt, a, t, lay, u_app);
+            if (STOR) store_rows_f32<kNpi>(a.f.u_opt, t, (unsigned)a.n_npi, lay, u_app);
             double A[M * M];
             state_jacobians<M, FLIP>(p, u_in, sk_plus, A);
             predict_cov_sym<M>(A, Pp, Qd, Pm);

@@ -469,32 +469,11 @@ constexpr int pinv_wg() { return M >= 6 ? 64 : 256; }
 // Three waves per SIMD (168 VGPRs): the third wave fills VALU issue slots two dependent fp64 chains leave idle (6.2 ->
 // 5.9 ms on the headline sweep with 76 B/lane of scratch; 5.8 ms and no scratch once the Jacobi's b/z accumulators
 // moved to LDS, 6 KB per wavefront).
+// X = pinv(P(t1|t1-1)) of chain c: the work of one lane of the grid below
 template <int M>
-__global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
+EPI_DEV void pinv_one(const KArgs &a, int c, int t1, double *plds)
 {
-    // grid: x = pinv_wg<M>()-chain tiles of the chain range (rounded up to a multiple of 8), y = step; a workgroup shares one
-    // step => uniform row bases
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear-id order, so
-    // XCD c gets ids c, c + 8, ...  Within EVERY step give each XCD a contiguous eighth of the tiles: neighbouring tiles --
-    // whose 64 chains share a partial cache line where they straddle a 40-chain layout block -- then meet in one L2, and all
-    // XCDs still walk the steps together (the early, full-rank steps cost three times the late ones).
-    const unsigned gx = gridDim.x;
-    const unsigned long long lin = (unsigned long long)blockIdx.y * gx + blockIdx.x;      // (2^17 tiles x 2^16 steps exceed 32 bits)
-    const unsigned per = gx >> 3;                              // tiles of a step per XCD (the grid's x extent is a multiple of 8)
-    const unsigned xcd = (unsigned)(lin & 7ull);
-    const unsigned long long k = lin >> 3;
-    unsigned by = blockIdx.y, bx = blockIdx.x;                 // fewer than 8 tiles: the launch keeps the plain order
-    if ((gx & 7u) == 0u) {
-        by = (unsigned)(k / per);
-        bx = xcd * per + (unsigned)(k - (unsigned long long)by * per);
-    }
-    const int cl = (int)(bx * blockDim.x + threadIdx.x);
-    if (cl >= a.cn) return;
-    const int B = a.B;
-    // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
-    const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)by;
-    const int c = a.c0 + cl;
-    if (a.only && !a.only[c]) return;
+    constexpr int WG = pinv_wg<M>();
     const Lay lay = make_lay(a, c);
     constexpr int NSX = M * (M + 1) / 2;
     double Pu[NSX];
@@ -517,9 +496,6 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     double Xu[NSX];
     bool capped, indef;
     // one LDS column per lane: scratch of the full-rank route, and later the b/z accumulators of the two-sided fall-back
-    constexpr int WG = pinv_wg<M>();
-    constexpr int LROWS = NSX > 2 * M ? NSX : 2 * M;
-    __shared__ double plds[LROWS * WG];
     int rank = sym_pinv_psd<M, WG>(Pu, Xu, &capped, &indef, plds + threadIdx.x);              // :215
     unsigned voff_x, rowb_x;
     const rsrc_t rx = lay_slice(a.X, t1, NSX, lay, voff_x, rowb_x);
@@ -555,6 +531,43 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
                 for (int i = 0; i <= j; i++) bst(rx, voff_x, (unsigned)(i + j * (j + 1) / 2) * rowb_x, X[IXM(i, j)]);
             *rword = rank2 | (capped2 ? 0x100 : 0);
         }
+    }
+}
+template <int M>
+__global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
+{
+    // grid: x = pinv_wg<M>()-chain tiles of the chain range (rounded up to a multiple of 8), y = step; a workgroup shares one
+    // step => uniform row bases
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in linear-id order, so
+    // XCD c gets ids c, c + 8, ...  Within EVERY step give each XCD a contiguous eighth of the tiles: neighbouring tiles --
+    // whose 64 chains share a partial cache line where they straddle a 40-chain layout block -- then meet in one L2, and all
+    // XCDs still walk the steps together (the early, full-rank steps cost three times the late ones).
+    const unsigned gx = gridDim.x;
+    const unsigned long long lin = (unsigned long long)blockIdx.y * gx + blockIdx.x;      // (2^17 tiles x 2^16 steps exceed 32 bits)
+    const unsigned per = gx >> 3;                              // tiles of a step per XCD (the grid's x extent is a multiple of 8)
+    const unsigned xcd = (unsigned)(lin & 7ull);
+    const unsigned long long k = lin >> 3;
+    unsigned by = blockIdx.y, bx = blockIdx.x;                 // fewer than 8 tiles: the launch keeps the plain order
+    if ((gx & 7u) == 0u) {
+        by = (unsigned)(k / per);
+        bx = xcd * per + (unsigned)(k - (unsigned long long)by * per);
+    }
+    constexpr int WG = pinv_wg<M>();
+    constexpr int NSX = M * (M + 1) / 2;
+    constexpr int LROWS = NSX > 2 * M ? NSX : 2 * M;
+    // one LDS column per lane: scratch of the full-rank route, and later the b/z accumulators of the two-sided fall-back
+    __shared__ double plds[LROWS * WG];
+    // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
+    const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)by;
+    // Second pass over the chains whose covariance went non-finite (epi_batch_desc.exact_nonfinite, a.only): the launch is a few
+    // tiles wide and walks the list mark_nonfinite left -- nothing to do, and next to nothing dispatched, when no chain is
+    // marked.  Otherwise lane `cl` of the grid has chain c0 + cl.  (One call site for both, so that the 60 KB body exists once.)
+    const int32_t *list = a.only ? a.only + a.B + 1 : nullptr;
+    const int count = a.only ? a.only[a.B] : a.cn;
+    const int stride = (int)(gx * blockDim.x);
+    for (int cl = (int)(bx * blockDim.x + threadIdx.x); cl < count; cl += stride) {
+        pinv_one<M>(a, list ? list[cl] : a.c0 + cl, t1, plds);
+        if (!list) break;
     }
 }
 
@@ -883,14 +896,15 @@ __global__ __launch_bounds__(256) void calib_copy_f64(const double *__restrict__
 }
 
 // epi_batch_desc.exact_nonfinite: only[c] = status bit 0 of chain c (the non-finite guard of GenericEKF.m:211 fired: its
-// covariance overflowed at some day), only[B] = how many chains that is
+// covariance overflowed at some day), only[B] = how many chains that is, only[B + 1 ...] = which (any order): the dense
+// second pass's pinv grid walks that list instead of testing every (chain, step) pair
 __global__ __launch_bounds__(256) void mark_nonfinite(const int32_t *__restrict__ status, int32_t *__restrict__ only, int B)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= B) return;
     const int v = status[c] & 1;
     only[c] = v;
-    if (v) atomicAdd(only + B, 1);
+    if (v) only[B + 1 + atomicAdd(only + B, 1)] = c;
 }
 
 // ---------------------------------------------------------------------------
@@ -1073,8 +1087,8 @@ static WsLayout ws_layout(const epi_batch_desc *d)
     w.hand_i = take(generic, Bp * sizeof(int32_t));
     // exact_nonfinite: the per-chain mask of the dense second pass (+ its counter) and a status array of the library's own
     // (the caller need not pass one)
-    w.only = take(generic && d->exact_nonfinite, (Bp + 1) * sizeof(int32_t));
-    w.status = take(generic && d->exact_nonfinite, Bp * sizeof(int32_t));
+    w.only = take(generic && d->exact_nonfinite >= 0, (2 * Bp + 1) * sizeof(int32_t));
+    w.status = take(generic && d->exact_nonfinite >= 0, Bp * sizeof(int32_t));
     w.total = off;
     return w;
 }
@@ -1147,6 +1161,12 @@ static hipError_t launch_monitor(const KArgs &ka, int dev, hipStream_t st)
     return hipGetLastError();
 }
 
+#ifndef EPI_FWD3_LEAN
+#define EPI_FWD3_LEAN 0
+#endif
+#ifndef EPI_FWD3_LDS_PAD
+#define EPI_FWD3_LDS_PAD 0          // probe: extra dynamic LDS per workgroup of the 3-state LP = 2 forward variant (caps its waves per SIMD)
+#endif
 // forward kernel(s) over filter steps [ka.k_begin, ka.k_end) of all chains
 template <int M, int FLIP, int GENERIC>
 static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
@@ -1215,7 +1235,19 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
             const bool lp = M == 6 && ka.lw <= kPipeLanes && per_lane * kPipeLanes * 4 <= 160u * 1024u;
             if (ka.mon_hoist) {         // no windows in LDS: only the LP variant's model vectors
                 const size_t lp_shm = (size_t)4 * kNpi * kPipeLanes * sizeof(double);
+#if EPI_FWD3_LEAN
+                // Measured and NOT adopted (round 5, verdict r04 item 3): the 3-state forward kernel with a, u_max in LDS and a day's
+                // controls consumed on arrival (LP = 2) needs 166 registers, no scratch -- THREE clean waves per SIMD -- and takes
+                // 11.4-11.8 ms on BASELINE config 5 against 8.8-9.5 for the 224-register kernel at two (capped at two waves by an LDS
+                // pad: 12.3): the 24 LDS reads a day on the alpha map's dependent chain cost more than the third wave returns
+                // (profiles/r05/ab_cfg5_three_waves.txt).  -DEPI_FWD3_LEAN=1 builds it.
+                if (ka.stor && M == 3 && ka.lw == kWave)
+                    hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, (M == 3 ? 2 : 0), 1, 0>), dim3(blocks), dim3(kWave), (size_t)2 * kNpi * kWave * sizeof(double) + EPI_FWD3_LDS_PAD, st, ka, ka.dense_flag);
+                else
+#endif
                 if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1, 0>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else if (lp && M == 6 && ka.ws_upper == 3)     // reduced outputs: the variant that fits two waves per SIMD (USD)
+                    hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1, 0, 0, 1>), dim3(blocks), dim3(kWave), lp_shm, st, ka, ka.dense_flag);
                 else if (lp) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 1, 0, 0>), dim3(blocks), dim3(kWave), lp_shm, st, ka, ka.dense_flag);
                 else hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 0, 0>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
             } else if (ka.stor) hipLaunchKernelGGL((ekf_fwd_sym<M, FLIP, 0, 1>), dim3(blocks), dim3(kWave), shmem, st, ka, ka.dense_flag);
@@ -1243,7 +1275,8 @@ static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st)
     if (nsteps <= 0) return hipSuccess;
     ka.c0 = 0; ka.cn = ka.B; ka.pinv_step0 = step0;
     // x extent rounded up to a multiple of 8: the kernel re-orders its tiles so that every XCD gets a contiguous eighth per step
-    const unsigned tiles = (unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>());
+    unsigned tiles = (unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>());
+    if (ka.only && tiles > 8u) tiles = 8u;      // the second pass of exact_nonfinite walks the list of marked chains (see eks_pinv)
     hipLaunchKernelGGL((eks_pinv<M>), dim3(tiles >= 8u ? ((tiles + 7u) & ~7u) : tiles, (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
     return hipGetLastError();
 }
@@ -1536,7 +1569,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->lane_block < 0) { set_err(err, "lane_block must be >= 0"); return EPI_ERR_BAD_ARG; }
     if (d->shape < 0 || d->shape > 4) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain), 2 (four lanes per chain), 3 (one wavefront per chain) or 4 (six lanes per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
-    if (d->exact_nonfinite < 0 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 or 1"); return EPI_ERR_BAD_ARG; }
+    if (d->exact_nonfinite < -1 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 (default: on), 1 (on) or -1 (off)"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
@@ -1635,8 +1668,12 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     ka.f.K_GAIN = sel32(EPI_OUT_K_GAIN, out->K_GAIN); ka.f.innovations = sel32(EPI_OUT_INNOVATIONS, out->innovations);
     ka.f.rho = sel32(EPI_OUT_RHO, out->rho);
     ka.pinv_rank = out->pinv_rank; ka.status = out->status;
-    const bool rerun = mi.generic && d->exact_nonfinite != 0 && d->q_mode == 0 && d->phase == 0 && !f32;
-    if (mi.generic && d->exact_nonfinite) {
+    // exact_nonfinite: 1 = always (runs the smoother to find the chains, whatever is selected); 0, the default = whenever the call
+    // runs the smoother anyway; -1 = never
+    const bool smooth_sel = ((om | om32) & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH)) ||
+                            out->pinv_rank || out->status;
+    const bool rerun = mi.generic && (d->exact_nonfinite > 0 || (d->exact_nonfinite == 0 && smooth_sel)) && d->q_mode == 0 && d->phase == 0 && !f32;
+    if (mi.generic && d->exact_nonfinite >= 0) {
         ka.only_buf = (int32_t *)(ws + wl.only);
         if (!ka.status && rerun) ka.status = (int32_t *)(ws + wl.status);
     }
@@ -1662,8 +1699,7 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
         if (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH) && !out->u_opt_smooth) { set_err(err, "output u_opt_smooth selected but NULL"); return EPI_ERR_BAD_ARG; }
     }
     // (exact_nonfinite needs the smoother's guard to find the chains: it runs the smoother whatever is selected)
-    const bool smooth = ((om | om32) & (EPI_OUT_S_SMOOTH | EPI_OUT_P_SMOOTH)) || (has_uos && ((om | om32) & EPI_OUT_U_OPT_SMOOTH)) ||
-                        out->pinv_rank || out->status || rerun;
+    const bool smooth = smooth_sel || rerun;
     hipStream_t st = (hipStream_t)stream;
     Launch L{};
     L.dev = dev; L.phase = d->phase; L.time_pipe = d->time_pipe; L.smooth = smooth; L.tail = tail; L.rerun = rerun;
@@ -1964,7 +2000,7 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     // with a synchronising download anyway, so the per-chain status words come back with it and the dense second pass is
     // enqueued only when one of them has bit 0 set: the common call pays nothing for it (the device-side variant costs five
     // launches that return at once, ~40 us of a 1.5 ms one-chain call).
-    d.exact_nonfinite = 0;
+    d.exact_nonfinite = -1;
     const bool id_x = !in->x_series, id_u = !in->u_series;      // identity series: one series per chain, sliced with the chains
     if (id_x) d.Sx = n;
     if (id_u) d.Su = n;
@@ -2015,7 +2051,7 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     if (out->status) o_stat = io.add_out(out->status, 1, 4, Bfull, lo, n);
     else if (watch) { own_status.assign((size_t)n, 0); hstat = own_status.data(); o_stat = io.add_out(own_status.data(), 1, 4, (size_t)n, 0, n); }
     epi_batch_desc dmax = d;
-    dmax.exact_nonfinite = watch ? 1 : 0;            // the workspace is sized for the second pass
+    dmax.exact_nonfinite = watch ? 1 : -1;           // the workspace is sized for the second pass
     const size_t wsb = epi_ekf_workspace_bytes(&dmax);
     const size_t o_ws = io.reserve(wsb);
     hipError_t e = cx->reserve(io.off + 256);

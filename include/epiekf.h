@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define EPIEKF_ABI_VERSION 4
+#define EPIEKF_ABI_VERSION 5
 
 /* which reference function the chain runs */
 typedef enum epi_model {
@@ -164,17 +164,20 @@ typedef struct epi_batch_desc {
                              register arithmetic (BASELINE config 5): every selected output is the fp64 result rounded
                              once to fp32; the forward quantities the smoother reads back stay fp64 in the workspace.
                              epi_ekf_run_device only. */
-    int32_t exact_nonfinite; /* 1: chains whose covariance overflows (status bit 0: the non-finite guard of GenericEKF.m:211
-                             fired) are run a second time by the dense kernels, in place, so that their Inf / NaN pattern is
-                             the dense evaluation's -- the reference's, and the C oracle's -- at every day.  The packed and
-                             quad kernels skip products with structural zeros, which is exact only for finite operands: after
-                             an overflow they may carry a finite number where MATLAB has NaN.  Generic models, full call
-                             (phase 0), fixed Q_w, fp64 storage; costs three launches that return at once when no chain is
-                             marked (~0.15 ms at 75 000 x 520) and needs (B + 1 + B) more int32 of workspace.  The *_host
-                             entry points give the same result at no cost to the common call: epi_ekf_run_host[_multi] look at
-                             the status words that come back with the outputs and enqueue the second pass only when a chain is
-                             marked (calls that select a smoothed output, pinv_rank or status); epi_sweep_prescribe_host sets
-                             the flag.  0: as the kernels leave them (`status` still tells which chains). */
+    int32_t exact_nonfinite; /* What happens to chains whose covariance overflows (status bit 0: the non-finite guard of
+                             GenericEKF.m:211 fired).  The packed, quad and hex kernels skip products with structural zeros,
+                             which is exact only for finite operands: after an overflow they may carry a finite number where
+                             MATLAB has NaN.  0 (the default, ABI 5) = the reference's behaviour whenever the call runs the
+                             smoother: the marked chains are run a second time by the dense kernels, in place, so that their
+                             Inf / NaN pattern is the dense evaluation's -- the reference's, and the C oracle's -- at every
+                             day; 1 = the same, and the smoother is run to find the chains even when no smoothed output is
+                             selected; -1 = off, the outputs are what the fast kernels leave (`status` still tells which
+                             chains).  Generic models, full call (phase 0), fixed Q_w, fp64 storage.  Cost when no chain is
+                             marked: six small launches that return at once (~25 us; until ABI 4 the second pass's pinv grid
+                             dispatched every (tile, step) workgroup -- 0.15 ms at 75 000 x 520 -- now it is 8 tiles wide and
+                             walks the list of marked chains); (2 B + 1 + B) more int32 of workspace.  The *_host entry points
+                             reach the same result without device-side launches: epi_ekf_run_host[_multi] look at the status
+                             words that come back with the outputs and enqueue the second pass only when a chain is marked. */
 } epi_batch_desc;
 
 typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3, EPI_SHAPE_HEX = 4 } epi_shape;

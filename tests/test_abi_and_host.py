@@ -85,6 +85,11 @@ def test_workspace_covers_unselected_forward_quantities(hip_lib):
     # hand-over rows between two backward launches (S_SMOOTH, P_SMOOTH, status word of one day)
     base = r256(4 * 10 * 8 * 21) + r256(4 * 10 * 4) + 256      # X is stored packed (21 of 36)
     base += r256(4 * 8 * 6) + r256(4 * 8 * 36) + r256(4 * 4)
+    off = _desc(model="SIAlphaModelEKFOptControlled"); off.exact_nonfinite = -1
+    assert hip_lib.epi_ekf_workspace_bytes(C.byref(off)) == base
+    # exact_nonfinite (the default, 0, and 1): the mask of the dense second pass, its counter, the list of marked chains, and a
+    # status array of the library's own
+    base += r256((2 * 4 + 1) * 4) + r256(4 * 4)
     full = hip_lib.epi_ekf_workspace_bytes(C.byref(_desc(model="SIAlphaModelEKFOptControlled")))
     assert full == base
     red = _desc(model="SIAlphaModelEKFOptControlled", out_mask=L.OUT_BITS["u_opt_smooth"] | L.OUT_BITS["S_SMOOTH"])

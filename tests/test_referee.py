@@ -127,3 +127,20 @@ def test_gates_catch_a_wrong_but_self_consistent_smoother():
         caught_drop += bool(f2)
     assert caught_drop == len(H.REFEREE_CASES), caught_drop
     assert caught_scale >= 5, caught_scale
+
+
+def test_inner_gate_catches_what_the_lapack_derived_gate_lets_through():
+    """Round 5: a smoother that loses five digits -- here the smoothed epidemic states off by a relative 1e-10, far inside the
+    frozen gate that LAPACK's error sets (2.7e-8 on this fixture) -- fails the inner gate, 100 x the distance the C oracle
+    stood at from the exact result when the fixture was frozen (4.5e-13)."""
+    name = "ref_cfg4_dead_400_120"
+    w, fx = H.load_referee(name)
+    got = H.oracle_batch(w)
+    assert float(fx["tol_S_SMOOTH_states"]) > 1e-8 and H.referee_inner_gate(fx, "S_SMOOTH_states") < 1e-10
+    ok, _ = H.referee_compare(w, got, fx, name)
+    assert not ok
+    bad = dict(got)
+    bad["S_SMOOTH"] = got["S_SMOOTH"].copy()
+    bad["S_SMOOTH"][:, :3] *= 1.0 + 1e-10
+    fails, _ = H.referee_compare(w, bad, fx, name)
+    assert fails and all("inner gate" in f[2] for f in fails), fails
