@@ -202,12 +202,12 @@ EPI_DEV void w_load_prm(QPrm &p, WaveNpi &n, const KArgs &a, int B, int c, const
 EPI_DEV double w_load_u(const double *pu, const WaveLane &w) { return w.npi ? *pu : 0.0; }
 // my NPI at state s: phi (OptControlled.m:49), the control applied (:50-58, strict >) and my slope-term contribution
 // (:107-114; 0.0 where the dense code adds nothing -- x - 0.0 == x, so the running sum keeps its bits)
-EPI_DEV void w_npi(const QPrm &p, const WaveNpi &n, double u, double s6, double &uapp, double &tterm)
+EPI_DEV void w_npi(const QPrm &p, const WaveNpi &n, double u, double s6, double &uapp, double &tterm, bool phi_ge = false)
 {
     const double gs6 = p.gamma * s6;
     const double phi = n.ew - gs6 * n.a;
     const bool free_u = is_nan(u);
-    uapp = free_u ? ((phi > 0.0) ? n.umin : n.umax) : u;
+    uapp = free_u ? ((phi_ge ? (phi >= 0.0) : (phi > 0.0)) ? n.umin : n.umax) : u;     // strict > (OptControlled.m:50), >= in NewCase...m:175
     tterm = (free_u && phi > -n.inv_sigma && phi < n.inv_sigma) ? n.term : 0.0;
 }
 // (gamma*a') * (u_max - u): `d` [12] = u_max(k) - u(k) as left in LDS by the NPI lanes
@@ -230,13 +230,23 @@ EPI_DEV double w_slope(const double *tt)
 // ---------------------------------------------------------------------------
 // forward pass: GenericExtendedKalmanFilter.m:98-169 (the monitor :172-179 is replayed by ekf_monitor)
 // ---------------------------------------------------------------------------
-template <int FLIP>
+// GEN = 0 (round 5): Tools/NewCaseEKFEstimatorWithOptimalNPI.m, the older fused filter -- P+ = (I - K C) P- / gamma (:64), nothing
+// symmetrised (so (C P)(j) and (P C')(j) differ: only the latter makes the gain), the running scalar R of :110-112, rho from
+// cc / R without eps (:108), phi >= 0 (:175); any Ps_init and Q_w (every lane owns its element).  Always with MON = 1.
+// MON = 1 (round 5): R_v is a scalar -- fixed, or adapted from the innovation statistics (GenericEKF.m:180-185, beta != 1:
+// testScripts/testPrescribeXPRIZE01.m:211) -- so the innovation monitor :172-179 cannot be replayed afterwards: it runs inline.
+// The chain's innovation is wave-uniform; the three L-sample windows are double-written rings in LDS (see qring_sum) that every
+// lane sums newest -> oldest for itself (the reads broadcast).  The adaptive R(k+1) depends on day k's sum, so the ~60 dependent
+// additions are on the day's critical path: 0.83 instead of 0.72 ms for one chain of 520 days -- against 1.25 in the quad shape,
+// which such calls took until now.
+template <int FLIP, int MON = 0, int LC = 0, int GEN = 1>
 __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
     // tiles are 64 entries so that every lane writes its slot unconditionally (lanes >= 36 own padding)
     __shared__ double sP[kWave], sT[kWave], sA[kWave], sGa[kNpi], sD[kWave], sTt[kWave];
-    if (*dense_flag) return;
+    extern __shared__ double wlds[];          // MON: three windows [3][2 L]
+    if (dense_flag && *dense_flag) return;   // (the NewCase models have no packed / dense choice: no flag)
     const int c = a.c0 + (int)blockIdx.x;
     if (c >= a.c0 + a.cn) return;
     const int B = a.B, T = a.T;
@@ -253,12 +263,24 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
     const WaveJac jc = w_jac_setup<FLIP>(p, w);
     const double v_bar = w_vgpr(a.prm[(size_t)EPI_PRM_V_BAR * B + c]);
     const double gamma = w_vgpr(a.prm[(size_t)EPI_PRM_GAMMA_EKF * B + c]);
+    const double beta = MON ? w_vgpr(a.prm[(size_t)EPI_PRM_BETA_EKF * B + c]) : 1.0;
 
     double sk_minus[M];
 #pragma unroll
     for (int i = 0; i < M; i++) sk_minus[i] = a.s_init[(size_t)i * B + c];
     double Pm = a.Ps_init[(size_t)w.e * B + c];
     const double Qe = a.Q[(size_t)w.e * B + c];
+    // the monitor's windows and the running R (see ekf_fwd_quad)
+    const int L = LC ? LC : a.L;        // LC > 0: the window length is that compile-time constant (21 is what every caller passes)
+    double *winMean = wlds, *winCov = wlds + 2 * L, *winCovN = wlds + 4 * L;
+    if (MON) {
+        for (int q = (int)lane; q < 6 * L; q += kWave) wlds[q] = 0.0;
+        __syncthreads();
+    }
+    int pos = 0;
+    const bool fixed_R = MON && a.r_mode == 0;
+    const double R_v = fixed_R ? a.R_scalar[c] : 0.0;
+    double R_next = R_v;
 
     const int k_begin = a.k_begin, k_end = (a.k_end > 0 && a.k_end < T) ? a.k_end : T;
     const int t0 = tpos<FLIP>(k_begin, T);
@@ -275,7 +297,8 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
     const double *pu = a.u + ((size_t)t0 * a.n_npi + (size_t)w.k) * a.Su + su;
     const long du = dir * (long)a.n_npi * a.Su;
     const long dx = dir * a.Sx;                           // x walks the caller's time axis, R_v the filter's (Backward*.m:27)
-    const double *px = a.x + (size_t)t0 * a.Sx + sx, *pr = a.R_series + (size_t)k_begin * a.Sx + sx;
+    const double *px = a.x + (size_t)t0 * a.Sx + sx, *pr = fixed_R ? px : a.R_series + (size_t)k_begin * a.Sx + sx;
+    double *pRho = (MON && a.rho) ? a.rho + lay_scalar(k_begin, lay) : nullptr;    // filter-step order also when FLIP
     if (k_begin > 0) {           // a later time segment resumes from what the previous one stored
         w_get_vec(pSm, blk, sk_minus);
         Pm = *pPm;
@@ -283,14 +306,15 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
         if (w.first) w_put_vec(pSm, blk, sk_minus);
         if (w.own) *pPm = Pm;
     }
-    double x_nxt = *px, r_nxt = *pr;
+    double x_nxt = *px, r_nxt = fixed_R ? 0.0 : *pr;
     double u_nxt = w_load_u(pu, w);
 
     for (int k = k_begin; k < k_end; k++) {
-        const double Rk = r_nxt, xk = x_nxt, u_in = u_nxt;
+        const double Rk = fixed_R ? R_next : r_nxt, xk = x_nxt, u_in = u_nxt;
         if (k + 1 < T) {
-            px += dx; pr += a.Sx; pu += du;
-            x_nxt = *px; r_nxt = *pr;
+            px += dx; pu += du;
+            x_nxt = *px;
+            if (!fixed_R) { pr += a.Sx; r_nxt = *pr; }
             u_nxt = w_load_u(pu, w);
         }
 
@@ -323,16 +347,22 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
                 ikc_j[q] = ((w.j == q) ? 1.0 : 0.0) - K_j * C[q];
             }
             const double T1 = w_dot6(ikc_i, pcol);                       // ((I - K C) P)(i,j)
-            sT[lane] = T1;
-            __syncthreads();
+            if (GEN) {
+                sT[lane] = T1;
+                __syncthreads();
+            }
 #pragma unroll
             for (int q = 0; q < M; q++) K[q] = w_bcast(K_i, q);          // lane q holds K(q)
 #pragma unroll
             for (int q = 0; q < M; q++) sk_plus[q] = sk_minus[q] + K[q] * innov;   // :129
-            double t1row[6];
-            w_row(sT, w.i, t1row);
-            const double T2 = w_dot6(t1row, ikc_j);                      // Joseph form :127
-            Pp = (T2 + (K_i * Rk) * K_j) / gamma;
+            if (GEN) {
+                double t1row[6];
+                w_row(sT, w.i, t1row);
+                const double T2 = w_dot6(t1row, ikc_j);                  // Joseph form :127
+                Pp = (T2 + (K_i * Rk) * K_j) / gamma;
+            } else {
+                Pp = T1 / gamma;                                         // NewCase...m:64
+            }
         } else {                                                         // :130-135
             innov = 0.0;
 #pragma unroll
@@ -342,9 +372,9 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
         state_hard_margins<M>(p, sk_plus);                               // :141
         // my NPI at s(k|k): the control applied and the slope-term contribution; my entry of the Jacobian  :155-157
         double u_app, tterm;
-        w_npi(p, np, u_in, sk_plus[5], u_app, tterm);
+        w_npi(p, np, u_in, sk_plus[5], u_app, tterm, a.mf.phi_ge != 0);
         const double myA = w_jac_entry(p, jc, sk_plus);
-        Pp = (Pp + w_from(Pp, tr_b)) / 2.0;                              // :138  (P + P')/2.0
+        if (GEN) Pp = (Pp + w_from(Pp, tr_b)) / 2.0;                     // :138  (P + P')/2.0
         __syncthreads();
         sP[lane] = Pp;                                                   // the symmetrised P(k|k)
         sA[lane] = myA;
@@ -368,7 +398,7 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
             w_row(sT, w.i, t1row);
             const double T2 = w_dot6(t1row, arow_j);                     // (A P+ A')(i,j)
             double Pn = T2 + Qe;                                         // B = I
-            Pn = (Pn + w_from(Pn, tr_b)) / 2.0;                          // :161
+            if (GEN) Pn = (Pn + w_from(Pn, tr_b)) / 2.0;                 // :161
             Pm = Pn;
         }
         state_hard_margins<M>(p, sk_next);                               // :164
@@ -392,6 +422,42 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_wave(const KArgs a, const int *
         if (pIn) pIn += d1;
 #pragma unroll
         for (int q = 0; q < M; q++) sk_minus[q] = sk_next[q];
+
+        if (!MON) continue;
+        // innovation monitor :172-179 and the adaptive R :180-185 (the arithmetic of ekf_fwd_quad / ekf_fwd_sym; every lane holds
+        // the same numbers, the LDS writes of the 64 lanes coincide)
+        const int cnt = (k + 1 < L) ? (k + 1) : L;
+        pos = (pos == 0) ? (L - 1) : (pos - 1);
+        double *wm = winMean + pos;
+        __syncthreads();
+        wm[0] = innov; wm[L] = innov;
+        __syncthreads();
+        const double sum = qring_sum<LC, 1>(wm, L, innov);
+        const double mu = sum / (double)cnt;
+        const double cc2 = (innov - mu) * (innov - mu);
+        const double ccn = GEN ? cc2 / (Rk + kEps) : cc2 / Rk;          // NewCase...m:108
+        double *wc = winCov + pos, *wn = winCovN + pos;
+        wc[0] = cc2; wc[L] = cc2;
+        wn[0] = ccn; wn[L] = ccn;
+        __syncthreads();
+        const double sumN = qring_sum<LC, 1>(wn, L, ccn);
+        if (pRho) {
+            if (w.first) *pRho = sumN / (double)cnt;
+            pRho += bp;
+        }
+        if (fixed_R) {
+            if (GEN) {
+                if (beta != 1.0 && valid && k < T - 1) {
+                    const double sumC = qring_sum<LC, 1>(wc, L, cc2);
+                    R_next = beta * Rk + (1.0 - beta) * (sumC / (double)cnt);      // :184
+                } else {
+                    R_next = R_v;
+                }
+            } else if (beta != 1.0 && valid) {                                     // NewCase...m:110-112: a running R
+                const double sumC = qring_sum<LC, 1>(wc, L, cc2);
+                R_next = beta * Rk + (1.0 - beta) * sumC / (double)cnt;
+            }
+        }
     }
 }
 
@@ -561,6 +627,225 @@ __global__ __launch_bounds__(kWave) void eks_bwd_wave(const KArgs a, const int *
         if (pPs && w.own) *pPs = Ps;
     }
     if (w.first && a.status) a.status[c] = st_guard | (st_cap << 1) | (min_rank << 8);
+}
+
+// ---------------------------------------------------------------------------
+// backward pass of NewCaseEKFEstimatorWithOptimalNPI (NewCase...m:115-139) in the wave shape (round 5)
+// ---------------------------------------------------------------------------
+// One row of X = Bm / A, i.e. of the solution of X A = Bm: A' x' = b' with b = Brow, by the operation order of mrdivide()
+// (ekf_device.hpp: LAPACK dgetf2 + dgetrs -- first-max partial pivoting with predicated swaps, reciprocal scaling of the
+// sub-column, column-oriented triangular solves).  The rows of X are independent given the factorisation, so lane c < 6 of the
+// wavefront factors A' for itself and solves for row c: ~1/4 of the instructions of the whole mrdivide per lane.
+template <int M>
+EPI_DEV void mrdivide_row(const double (&Brow)[M], const double (&A)[M * M], double (&Xrow)[M])
+{
+    double Mt[M * M], Y[M];
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+#pragma unroll
+        for (int i = 0; i < M; i++) Mt[IXM(i, j)] = A[IXM(j, i)];
+        Y[j] = Brow[j];
+    }
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        int piv = j;
+        double best = fabs(Mt[IXM(j, j)]);
+#pragma unroll
+        for (int i = j + 1; i < M; i++) {
+            double vv = fabs(Mt[IXM(i, j)]);
+            if (vv > best) { best = vv; piv = i; }
+        }
+        double pval = Mt[IXM(j, j)];
+#pragma unroll
+        for (int i = j + 1; i < M; i++) pval = (piv == i) ? Mt[IXM(i, j)] : pval;
+        const bool nz = (pval != 0.0);
+#pragma unroll
+        for (int i = j + 1; i < M; i++) {
+            const bool sw = (piv == i);
+            if (__builtin_amdgcn_ballot_w64(sw) == 0ull) continue;
+#pragma unroll
+            for (int c = 0; c < M; c++) {
+                double mj = Mt[IXM(j, c)], mi = Mt[IXM(i, c)];
+                Mt[IXM(j, c)] = (sw && nz) ? mi : mj;
+                Mt[IXM(i, c)] = (sw && nz) ? mj : mi;
+            }
+            double yj = Y[j], yi = Y[i];
+            Y[j] = sw ? yi : yj;
+            Y[i] = sw ? yj : yi;
+        }
+        if (nz) {
+            if (fabs(Mt[IXM(j, j)]) >= 2.2250738585072014e-308) {
+                const double r = 1.0 / Mt[IXM(j, j)];
+#pragma unroll
+                for (int i = j + 1; i < M; i++) Mt[IXM(i, j)] = Mt[IXM(i, j)] * r;
+            } else {
+#pragma unroll
+                for (int i = j + 1; i < M; i++) Mt[IXM(i, j)] = Mt[IXM(i, j)] / Mt[IXM(j, j)];
+            }
+        }
+#pragma unroll
+        for (int c = j + 1; c < M; c++)
+#pragma unroll
+            for (int i = j + 1; i < M; i++) Mt[IXM(i, c)] = Mt[IXM(i, c)] - Mt[IXM(i, j)] * Mt[IXM(j, c)];
+    }
+#pragma unroll
+    for (int k = 0; k < M; k++) {
+        if (Y[k] != 0.0) {
+#pragma unroll
+            for (int i = k + 1; i < M; i++) Y[i] = Y[i] - Y[k] * Mt[IXM(i, k)];
+        }
+    }
+#pragma unroll
+    for (int k = M - 1; k >= 0; k--) {
+        if (Y[k] != 0.0) {
+            Y[k] = Y[k] / Mt[IXM(k, k)];
+#pragma unroll
+            for (int i = 0; i < k; i++) Y[i] = Y[i] - Y[k] * Mt[IXM(i, k)];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < M; i++) Xrow[i] = Y[i];
+}
+
+// Same lane mapping as eks_bwd_wave.  What differs (NewCase...m:115-139): the terminal condition's cross-product sub-assignment
+// (:125-127), the gain J = (P+ A') / P- by mrdivide -- the six lanes c < 6 each solve for row c of J, see mrdivide_row --, no
+// symmetrisation, no u_opt_smooth, no rank words.
+__global__ __launch_bounds__(kWave) void eks_bwd_wave_nc(const KArgs a)
+{
+    constexpr int M = 6;
+    constexpr int FLIP = 0;
+    __shared__ double sP[kWave], sT[kWave], sA[kWave], sM[kWave], sJ[kWave], sGa[kNpi], sTt[kWave];
+    const int c = a.c0 + (int)blockIdx.x;
+    if (c >= a.c0 + a.cn) return;
+    const int B = a.B, T = a.T;
+    const int su = a.u_series ? a.u_series[c] : c;
+    const Lay lay = make_lay(a, c);
+    const WaveLane w = w_lane(a);
+    const unsigned lane = threadIdx.x;
+    QPrm p;
+    WaveNpi np;
+    w_load_prm(p, np, a, B, c, w, sGa);
+    const WaveJac jc = w_jac_setup<FLIP>(p, w);
+    const unsigned blk = lay.blk;
+    const long bp = (long)lay.bp;
+    const long dir = -1L;                                // the smoother walks DOWN the filter's time axis
+
+    // terminal condition :117-127
+    const int tT = T - 1;
+    double Ss[M], Ps;
+    w_get_vec(a.S_PLUS + w_elem(lay, tT, 6u, 0u), blk, Ss);
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const double f = a.s_final[(size_t)i * B + c];
+        if (!is_nan(f)) Ss[i] = f;
+    }
+    Ps = a.P_PLUS[w_elem(lay, tT, 36u, (unsigned)w.e)];
+    {
+        // P_SMOOTH(row, col, T) = Ps_final(row, col) for the rows and columns that hold any non-NaN entry
+        const double f = a.Ps_final[(size_t)w.e * B + c];
+        sT[lane] = (w.own && !is_nan(f)) ? 1.0 : 0.0;
+        __syncthreads();
+        double fr[6], fc[6];
+        w_row(sT, w.i, fr);
+        w_col(sT, w.j, fc);
+        bool rows = false, cols = false;
+#pragma unroll
+        for (int q = 0; q < M; q++) { rows = rows || fr[q] != 0.0; cols = cols || fc[q] != 0.0; }
+        if (rows && cols) Ps = f;
+        __syncthreads();
+    }
+    double *pSs = a.S_SMOOTH ? a.S_SMOOTH + w_elem(lay, tT, 6u, 0u) : nullptr;
+    double *pPs = a.P_SMOOTH ? a.P_SMOOTH + w_elem(lay, tT, 36u, (unsigned)w.e) : nullptr;
+    int32_t *pRk = a.pinv_rank ? a.pinv_rank + lay_scalar(tT, lay) : nullptr;
+    if (w.first) {
+        if (pSs) w_put_vec(pSs, blk, Ss);
+        if (pRk) *pRk = -1;
+    }
+    if (pPs && w.own) *pPs = Ps;
+    const long d6 = dir * 6 * bp, d36 = dir * 36 * bp, d1 = dir * bp;
+    const long du = dir * (long)a.n_npi * a.Su;
+
+    WaveBwdIn nxt;
+    WaveBwdPtr q;
+    auto fetch = [&](WaveBwdIn &o) __attribute__((always_inline)) {
+        w_get_vec(q.Sp, blk, o.Sp);
+        w_get_vec(q.Sm1, blk, o.Sm1);
+        o.Pp = *q.Pp;
+        o.Pm1 = *q.Pm1;
+        o.u = w_load_u(q.u, w);
+    };
+    if (T >= 2) {
+        const int t = T - 2;
+        q.Sp = a.S_PLUS + w_elem(lay, t, 6u, 0u); q.Sm1 = a.S_MINUS + w_elem(lay, tT, 6u, 0u);
+        q.Pp = a.P_PLUS + w_elem(lay, t, 36u, (unsigned)w.e); q.Pm1 = a.P_MINUS + w_elem(lay, tT, 36u, (unsigned)w.e);
+        q.u = a.u + ((size_t)t * a.n_npi + (size_t)w.k) * a.Su + su;
+        fetch(nxt);
+    }
+    for (int k = T - 2; k >= 0; k--) {
+        const WaveBwdIn cur = nxt;
+        if (pSs) pSs += d6;
+        if (pPs) pPs += d36;
+        if (pRk) pRk += d1;
+        if (k > 0) {
+            q.Sp += d6; q.Sm1 += d6; q.Pp += d36; q.Pm1 += d36; q.u += du;
+            fetch(nxt);
+        }
+        double u_unused, tterm;
+        w_npi(p, np, cur.u, cur.Sp[5], u_unused, tterm, a.mf.phi_ge != 0);
+        const double myA = w_jac_entry(p, jc, cur.Sp);
+        __syncthreads();
+        sTt[lane] = tterm;
+        sA[lane] = myA;
+        sP[lane] = cur.Pp; sM[lane] = cur.Pm1;
+        __syncthreads();
+        {
+            double pprow[6], arow_i[6], arow_j[6];
+            w_row(sP, w.i, pprow);
+            w_jac_rows(sA, w, w_slope<FLIP>(sTt), arow_i, arow_j);
+            sT[lane] = w_dot6(pprow, arow_j);                            // (P+ A')(i,j)
+        }
+        __syncthreads();
+        if (lane < M) {                                                  // J = (P+ A') / P-(k+1)  :132, row `lane`
+            double Am[M * M], brow[M], xrow[M];
+#pragma unroll
+            for (int e = 0; e < M * M; e++) Am[e] = sM[e];
+            w_row(sT, (int)lane, brow);
+            mrdivide_row<M>(brow, Am, xrow);
+#pragma unroll
+            for (int qq = 0; qq < M; qq++) sJ[lane + 6 * qq] = xrow[qq];
+        }
+        // S_SMOOTH(k) = clamp(S+ + J (S_SMOOTH(k+1) - S-(k+1)))   :134-135
+        double dv[M];
+#pragma unroll
+        for (int qq = 0; qq < M; qq++) dv[qq] = Ss[qq] - cur.Sm1[qq];
+        sP[lane] = cur.Pm1 - Ps;                                         // D = P_MINUS(k+1) - P_SMOOTH(k+1)
+        __syncthreads();
+        double jrow_i[6], jrow_j[6], dcol[6];
+        w_row(sJ, w.i, jrow_i);
+        w_row(sJ, w.j, jrow_j);
+        w_col(sP, w.j, dcol);
+        const double Jd_i = w_dot6(jrow_i, dv);
+        const double T1 = w_dot6(jrow_i, dcol);                          // (J D)(i,j)
+        __syncthreads();
+        sT[lane] = T1;
+        __syncthreads();
+        double Sn[M];
+#pragma unroll
+        for (int qq = 0; qq < M; qq++) Sn[qq] = cur.Sp[qq] + w_bcast(Jd_i, qq);   // lane q holds (J d)(q)
+        state_hard_margins<M>(p, Sn);
+        double t1row[6];
+        w_row(sT, w.i, t1row);
+        const double T2 = w_dot6(t1row, jrow_j);                         // (J D J')(i,j)
+        Ps = cur.Pp - T2;                                                // :137, not symmetrised
+#pragma unroll
+        for (int qq = 0; qq < M; qq++) Ss[qq] = Sn[qq];
+        if (w.first) {
+            if (pSs) w_put_vec(pSs, blk, Ss);
+            if (pRk) *pRk = -1;
+        }
+        if (pPs && w.own) *pPs = Ps;
+    }
+    if (w.first && a.status) a.status[c] = 0 | (0 << 1) | (M << 8);
 }
 
 // =====================================================================================================================

@@ -1037,7 +1037,16 @@ static bool monitor_hoisted(const epi_batch_desc *d)
 static int shape_of(const epi_batch_desc *d, int dev)
 {
     const ModelInfo &mi = MODEL_TABLE[d->model];
-    if (!mi.generic || d->storage) return EPI_SHAPE_LANE;
+    if (!mi.generic) {
+        // NewCaseEKFEstimatorWithOptimalNPI (round 5): one wavefront per chain (ekf_fwd_wave<0, 1, LC, 0>, eks_bwd_wave_nc) while every
+        // chain can have a SIMD of its own -- the reference's own callers make ONE call per chain
+        // (testScripts/testSIModelOptimalControl04EKS.m:168,302): 2.1 instead of 8.4 ms -- otherwise the dense one-lane kernels
+        const bool ok = mi.m == 6 && !d->storage && d->q_mode == 0 && (size_t)6 * d->L * sizeof(double) <= 48u * 1024u;
+        if (d->shape == EPI_SHAPE_WAVE) return ok ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
+        if (d->shape != EPI_SHAPE_AUTO) return EPI_SHAPE_LANE;
+        return (ok && (long)d->B <= (long)simd_count(dev)) ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
+    }
+    if (d->storage) return EPI_SHAPE_LANE;
     if (mi.m == 3) {
         // 3-state models: seven chains per wavefront, nine lanes each (ekf_fwd_wave3), for small batches; otherwise one lane
         // per chain.  There is no four-lane shape for them.  Measured (BASELINE config 3's chains x 400 days, ms per pass,
@@ -1049,14 +1058,19 @@ static int shape_of(const epi_batch_desc *d, int dev)
         if (d->shape == EPI_SHAPE_LANE || d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_HEX) return EPI_SHAPE_LANE;
         return (ok && d->B <= 2048) ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
     }
-    const bool wave_ok = monitor_hoisted(d);       // the wave and hex shapes need the monitor as its own kernel and a fixed Q_w
+    const bool hex_ok = monitor_hoisted(d);        // the hex shape needs the monitor as its own kernel (R_v a per-day series) and a fixed Q_w
+    // the wave shape also runs the monitor inline (a scalar, possibly adaptive R_v: ekf_fwd_wave<FLIP, 1>, round 5)
+    const bool wave_ok = hex_ok || (mi.generic && d->r_mode == 0 && d->q_mode == 0 && d->path_hint != 2 &&
+                                    (size_t)6 * d->L * sizeof(double) <= 48u * 1024u);
     if (d->shape == EPI_SHAPE_WAVE) return wave_ok ? EPI_SHAPE_WAVE : EPI_SHAPE_QUAD;
-    if (d->shape == EPI_SHAPE_HEX) return wave_ok ? EPI_SHAPE_HEX : EPI_SHAPE_QUAD;
+    if (d->shape == EPI_SHAPE_HEX) return hex_ok ? EPI_SHAPE_HEX : EPI_SHAPE_QUAD;
     if (d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_LANE) return d->shape;
-    if (wave_ok && (long)d->B <= (long)simd_count(dev)) return EPI_SHAPE_WAVE;
+    // (round 5: with the hex shape there, one wavefront per chain wins only up to ~600 chains: 300 chains 1.59 against 1.81 ms per
+    // call, 1 024 chains 2.15 against 1.84 -- profiles/r05/shape_latency.json; where the hex shape cannot run, up to one chain per SIMD)
+    if (wave_ok && (long)d->B <= (hex_ok ? (long)simd_count(dev) * 5 / 8 : (long)simd_count(dev))) return EPI_SHAPE_WAVE;
     // round 5: six lanes per chain, ten chains per wavefront (ekf_hex.hpp) while every such wavefront can have a SIMD of its own
     // (B <= 10 240 on MI355X: the 9 375-chain shard of the headline sweep on one of 8 GPUs)
-    if (wave_ok && ((long)d->B + kHG - 1) / kHG <= (long)simd_count(dev)) return EPI_SHAPE_HEX;
+    if (hex_ok && ((long)d->B + kHG - 1) / kHG <= (long)simd_count(dev)) return EPI_SHAPE_HEX;
     return ((long)d->B + kQC - 1) / kQC <= (long)simd_count(dev) ? EPI_SHAPE_QUAD : EPI_SHAPE_LANE;
 }
 
@@ -1178,11 +1192,21 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
     // hint 0: both variants are enqueued, the one ekf_precheck did not select returns at once
     const bool run_sym = GENERIC && L.hint != 2, run_dense = !GENERIC || L.hint != 1;
     hipError_t e = hipSuccess;
+    if constexpr (M == 6 && !GENERIC) {
+        if (ka.wave && !ka.only) {  // NewCaseEKFEstimatorWithOptimalNPI, one wavefront per chain (monitor always inline)
+            const size_t wshm = (size_t)6 * ka.L * sizeof(double);
+            if (ka.L == 21) hipLaunchKernelGGL((ekf_fwd_wave<0, 1, 21, 0>), dim3((unsigned)ka.B), dim3(kWave), wshm, st, ka, (const int *)nullptr);
+            else hipLaunchKernelGGL((ekf_fwd_wave<0, 1, 0, 0>), dim3((unsigned)ka.B), dim3(kWave), wshm, st, ka, (const int *)nullptr);
+            return hipGetLastError();
+        }
+    }
     if (run_sym) {
         bool done = false;
         if constexpr (M == 6 && GENERIC) {
-            if (ka.wave) {          // one wavefront per chain (ekf_wave.hpp)
-                hipLaunchKernelGGL((ekf_fwd_wave<FLIP>), dim3((unsigned)ka.B), dim3(kWave), 0, st, ka, ka.dense_flag);
+            if (ka.wave) {          // one wavefront per chain (ekf_wave.hpp); with a scalar R_v the monitor runs inline
+                if (ka.mon_hoist) hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 0>), dim3((unsigned)ka.B), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else if (ka.L == 21) hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 1, 21>), dim3((unsigned)ka.B), dim3(kWave), (size_t)6 * ka.L * sizeof(double), st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 1, 0>), dim3((unsigned)ka.B), dim3(kWave), (size_t)6 * ka.L * sizeof(double), st, ka, ka.dense_flag);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 done = true;
             }
@@ -1290,6 +1314,12 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
     const int blocks = (ka.B + ka.lw - 1) / ka.lw;
     const bool run_sym = GENERIC && L.hint != 2, run_dense = !GENERIC || L.hint != 1;
     hipError_t e = hipSuccess;
+    if constexpr (M == 6 && !GENERIC) {
+        if (ka.wave && !ka.only) {
+            hipLaunchKernelGGL(eks_bwd_wave_nc, dim3((unsigned)ka.B), dim3(kWave), 0, st, ka);
+            return hipGetLastError();
+        }
+    }
     if (run_sym) {
         bool done = false;
         if constexpr (M == 6 && GENERIC) {
