@@ -343,18 +343,17 @@ EPI_DEV void hx_load_col(const double *__restrict__ src, int t, const Lay &l, in
 // ---------------------------------------------------------------------------
 struct HexFwdIn { double x, r, u[2]; };
 
-template <int FLIP, int BLK>
+// SOLO = 1: the kernel claims more than half of the register file (a clobbered accumulation register), so that two of its waves
+// never share a SIMD while other SIMDs idle -- with its 235 registers the dispatcher otherwise packs them two to a SIMD here and
+// there, and the launch ends with the slowest pair (forward stage of the 9 375-chain shard 1.23-1.28 -> 1.02-1.03 ms; the first
+// version of the kernel, bound by its stores, did not care).  SOLO = 0 for grids beyond one wave per SIMD.
+template <int FLIP, int BLK, int SOLO = 0>
 __global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
     __shared__ __attribute__((aligned(16))) double tA[kHGp * kHT], tB[kHGp * kHT], tC[kHGp * kHT], tD[kHGp * kHT];
     __shared__ __attribute__((aligned(16))) double vPC[kHGp * kHV], vK[kHGp * kHV], vD[kHGp * kHN], vTm[kHGp * kHN];
-#ifdef EPI_HEX_SOLO
-    asm volatile("" ::: "a60");                // probe: more than 256 registers, so that two of these waves never share a SIMD
-#endif
-#ifdef EPI_HEX_PRIO
-    __builtin_amdgcn_s_setprio(3);             // probe: the latency-bound forward waves ahead of co-resident pinv waves
-#endif
+    if (SOLO) asm volatile("" ::: "a60");
     if (*dense_flag) return;
     const HexLane h = hx_lane(a);
     const int B = a.B, T = a.T, c = h.c, j = h.j;
@@ -540,20 +539,36 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *_
 #ifndef EPI_HEX_SHARE_LOADS
 #define EPI_HEX_SHARE_LOADS 1
 #endif
+// EPI_HEX_BWD_RECOMPUTE: P(k+1|k) is NOT read back: it is formed again from the P(k|k), S+(k), u(k) the step loads anyway, by
+// the forward kernel's own instruction sequence (hx_mul_A, the two transposes, + Q, the symmetrisation) -- the same bits -- and
+// its first product A P(k|k) is the (P+ A') row the gain needs in any case.  The smoother of this shape moves 6.2 GB in 1.30 ms
+// at the 9 375-chain shard, the box's copy rate, with its vector unit busy 29 % of the time: 288 of its 1 272 bytes per step
+// for 27 fma and two LDS transposes.  (The one-lane kernels lost with this in rounds 1-2: they pay every instruction.)
+#ifndef EPI_HEX_BWD_RECOMPUTE
+#define EPI_HEX_BWD_RECOMPUTE 1
+#endif
+
 #if EPI_HEX_SHARE_LOADS
 struct HexBwdIn { double Spj, Sm1j, u[2], Ppc[6], Pm1c[6], Xp[4]; int rk; };
 #else
 struct HexBwdIn { double Sp[6], Sm1[6], u[2], Ppc[6], Pm1c[6], X[21]; int rk; };
 #endif
 
-template <int FLIP, int BLK>
+// PF = 1: a step's inputs are requested one step ahead into one of two register sets (256 + 22 registers: one wave per SIMD) --
+// for launches of at most one wave per SIMD; PF = 0: requested at the start of the step (242 registers, no accumulation
+// registers: TWO waves per SIMD, which hide each other's memory latency) -- for larger launches.
+template <int FLIP, int BLK, int PF = 1>
 __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
     __shared__ __attribute__((aligned(16))) double tJ[kHGp * kHT], tB[kHGp * kHT], tC[kHGp * kHT];
     __shared__ __attribute__((aligned(16))) double vS[kHGp * kHV], vTm[kHGp * kHN];
+
 #if EPI_HEX_SHARE_LOADS
     __shared__ __attribute__((aligned(16))) double vSp[kHGp * kHV], vSm[kHGp * kHV], tXs[kHGp * 24];
+#endif
+#ifdef EPI_HEX_BWD_PRIO
+    __builtin_amdgcn_s_setprio(3);             // probe: the smoother's waves ahead of the pinv waves beside them
 #endif
     if (*dense_flag) return;
     const HexLane h = hx_lane(a);
@@ -562,6 +577,12 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
     const Lay lay = make_lay(a, c);
     double *tJg = tJ + kHT * h.g, *tBg = tB + kHT * h.g, *tCg = tC + kHT * h.g;
     double *vSg = vS + kHV * h.g, *vTmg = vTm + kHN * h.g;
+#if EPI_HEX_BWD_RECOMPUTE
+    double *tDg = tBg, *tEg = tCg;               // the recomputation's two transposes come before the recursion's: same tiles
+    double Qv[M];
+#pragma unroll
+    for (int i = 0; i < M; i++) Qv[i] = (i == j) ? a.Q[(size_t)IXM(j, j) * B + c] : 0.0;   // Q_w diagonal (ekf_precheck): row j of it
+#endif
 #if EPI_HEX_SHARE_LOADS
     double *vSpg = vSp + kHV * h.g, *vSmg = vSm + kHV * h.g, *tXg = tXs + 24 * h.g;
 #endif
@@ -628,7 +649,9 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
             d.Xp[3] = hx_ld<BLK>(r, voff + (unsigned)(j < 3 ? j : 2) * rowb, 18u, rowb);     // packed entries 18..20 exist for j < 3
         }
         d.Sm1j = hx_load_elem<BLK>(a.S_MINUS, t1, lay, j);
+#if !EPI_HEX_BWD_RECOMPUTE
         hx_load_col<BLK>(a.P_MINUS, t1, lay, j, d.Pm1c);
+#endif
 #else
         hx_load_vec<BLK>(a.S_PLUS, t, lay, d.Sp);
         hx_load_u(a, t, su, j, d.u);
@@ -641,7 +664,9 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
             for (int e = 0; e < 21; e++) d.X[e] = hx_ld<BLK>(r, voff, (unsigned)e, rowb);
         }
         hx_load_vec<BLK>(a.S_MINUS, t1, lay, d.Sm1);
+#if !EPI_HEX_BWD_RECOMPUTE
         hx_load_col<BLK>(a.P_MINUS, t1, lay, j, d.Pm1c);
+#endif
 #endif
     };
     auto step = [&](int k, const HexBwdIn &cur) __attribute__((always_inline)) {
@@ -677,6 +702,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
         double Jr[M];
         int rank = -1;
         const bool guard = cur.rk < 0;                                      // non-finite P_MINUS guard :211-213 (per chain)
+        double Pm1c[M];
         {
             double PAr[M];
             hx_mul_A(A, cur.Ppc, PAr);                                      // (P+ A')(j, i) = sum_q P+(j, q) A(i, q)
@@ -687,6 +713,20 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
                 for (int q = 1; q < M; q++) acc = fma(PAr[q], X[sidx(q, i)], acc);
                 Jr[i] = guard ? 0.0 : acc;
             }
+#if EPI_HEX_BWD_RECOMPUTE
+            // P(k+1|k) = sym(A P+ A' + Q) exactly as ekf_fwd_hex formed it: (A P+)(:, j) is PAr
+            double Tr[M], Gr[M], Gc[M];
+            hx_transpose(tDg, j, PAr, Tr);
+            hx_mul_A(A, Tr, Gr);
+#pragma unroll
+            for (int i = 0; i < M; i++) Gr[i] = Gr[i] + Qv[i];
+            hx_transpose(tEg, j, Gr, Gc);
+#pragma unroll
+            for (int i = 0; i < M; i++) Pm1c[i] = (Gc[i] + Gr[i]) / 2.0;
+#else
+#pragma unroll
+            for (int i = 0; i < M; i++) Pm1c[i] = cur.Pm1c[i];
+#endif
         }
         if (guard) st_guard = 1;
         else {
@@ -716,7 +756,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
             hx_fence();
             hx_get_all(tJg, Jall);                                          // Jall[6 i + q] = J(i, q)
 #pragma unroll
-            for (int i = 0; i < M; i++) Dc[i] = cur.Pm1c[i] - Psc[i];       // D(:, j)
+            for (int i = 0; i < M; i++) Dc[i] = Pm1c[i] - Psc[i];           // D(:, j)
 #pragma unroll
             for (int i = 0; i < M; i++) {                                   // (J D)(:, j)
                 double acc = Jall[6 * i] * Dc[0];
@@ -747,6 +787,13 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
             hx_store_u<BLK>(a.u_opt_smooth, a, t, lay, h, ur);
         }
     };
+    if constexpr (!PF) {
+        for (int k = k_from; k >= k_to; k--) {
+            HexBwdIn cur;
+            fetch(k, cur);
+            step(k, cur);
+        }
+    } else
     // two input sets used alternately (the loop body exists twice): the prefetched values are consumed where they landed
     {
         HexBwdIn bufA, bufB;

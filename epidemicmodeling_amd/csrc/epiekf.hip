@@ -533,7 +533,7 @@ EPI_DEV void pinv_one(const KArgs &a, int c, int t1, double *plds)
         }
     }
 }
-template <int M>
+template <int M, int LIST = 0>
 __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
 {
     // grid: x = pinv_wg<M>()-chain tiles of the chain range (rounded up to a multiple of 8), y = step; a workgroup shares one
@@ -559,16 +559,18 @@ __global__ __launch_bounds__(pinv_wg<M>(), 3) void eks_pinv(const KArgs a)
     __shared__ double plds[LROWS * WG];
     // array positions of filter steps 2..T: 1..T-1, or 0..T-2 for the time-flipped models (pinv_pos0 = 0)
     const int t1 = a.pinv_pos0 + a.pinv_step0 + (int)by;
-    // Second pass over the chains whose covariance went non-finite (epi_batch_desc.exact_nonfinite, a.only): the launch is a few
-    // tiles wide and walks the list mark_nonfinite left -- nothing to do, and next to nothing dispatched, when no chain is
-    // marked.  Otherwise lane `cl` of the grid has chain c0 + cl.  (One call site for both, so that the 60 KB body exists once.)
-    const int32_t *list = a.only ? a.only + a.B + 1 : nullptr;
-    const int count = a.only ? a.only[a.B] : a.cn;
-    const int stride = (int)(gx * blockDim.x);
-    for (int cl = (int)(bx * blockDim.x + threadIdx.x); cl < count; cl += stride) {
-        pinv_one<M>(a, list ? list[cl] : a.c0 + cl, t1, plds);
-        if (!list) break;
+    if (LIST) {
+        // Second pass over the chains whose covariance went non-finite (epi_batch_desc.exact_nonfinite, a.only): the launch is a
+        // few tiles wide and walks the list mark_nonfinite left -- nothing to do, and next to nothing dispatched, when no chain
+        // is marked.  (A kernel of its own: the loop around the 60 KB body costs the main grid 16 B of scratch per lane.)
+        const int32_t *list = a.only + a.B + 1;
+        const int count = a.only[a.B];
+        for (int cl = (int)(bx * blockDim.x + threadIdx.x); cl < count; cl += (int)(gx * blockDim.x)) pinv_one<M>(a, list[cl], t1, plds);
+        return;
     }
+    const int cl = (int)(bx * blockDim.x + threadIdx.x);
+    if (cl >= a.cn) return;
+    pinv_one<M>(a, a.c0 + cl, t1, plds);
 }
 
 // ---------------------------------------------------------------------------
@@ -935,7 +937,7 @@ static size_t padded_chains(const epi_batch_desc *d)
 // epi_host_pool_release): the SIMD count of each device, and idle helper streams
 // ---------------------------------------------------------------------------
 constexpr int kMaxDevices = 64;
-constexpr int kHelperEvents = 12;
+constexpr int kHelperEvents = 16;
 // A helper stream of the LOWEST priority (its workgroups are placed after the caller's stream's) with the events one call
 // needs to fork work onto it and join it back.  A call leases one for the time it takes to ENQUEUE its kernels; work of
 // consecutive lessees simply queues up on the stream.
@@ -1068,9 +1070,11 @@ static int shape_of(const epi_batch_desc *d, int dev)
     // (round 5: with the hex shape there, one wavefront per chain wins only up to ~600 chains: 300 chains 1.59 against 1.81 ms per
     // call, 1 024 chains 2.15 against 1.84 -- profiles/r05/shape_latency.json; where the hex shape cannot run, up to one chain per SIMD)
     if (wave_ok && (long)d->B <= (hex_ok ? (long)simd_count(dev) * 5 / 8 : (long)simd_count(dev))) return EPI_SHAPE_WAVE;
-    // round 5: six lanes per chain, ten chains per wavefront (ekf_hex.hpp) while every such wavefront can have a SIMD of its own
-    // (B <= 10 240 on MI355X: the 9 375-chain shard of the headline sweep on one of 8 GPUs)
-    if (hex_ok && ((long)d->B + kHG - 1) / kHG <= (long)simd_count(dev)) return EPI_SHAPE_HEX;
+    // round 5: six lanes per chain, ten chains per wavefront (ekf_hex.hpp) up to 1.5 such wavefronts per SIMD (15 360 chains on
+    // MI355X; beyond one per SIMD its kernels run two waves per SIMD): 9 375 chains -- the shard of the headline sweep on one of 8
+    // GPUs -- 2.8 ms against 3.1 (quad) and 4.9 (lane), 12 500 chains 3.9-4.0 against 5.0 (lane), 18 750 level with the lane shape
+    // (5.64 against 5.70), 20 480 behind it (6.07 against 5.85): profiles/r05/hex_ab.txt
+    if (hex_ok && 2 * (((long)d->B + kHG - 1) / kHG) <= 3 * (long)simd_count(dev)) return EPI_SHAPE_HEX;
     return ((long)d->B + kQC - 1) / kQC <= (long)simd_count(dev) ? EPI_SHAPE_QUAD : EPI_SHAPE_LANE;
 }
 
@@ -1157,7 +1161,7 @@ static hipError_t launch_monitor(const KArgs &ka, int dev, hipStream_t st)
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
     const int mb = (ka.B + kWave - 1) / kWave;
 #ifndef EPI_MONITOR_PAR_MAX_WAVES
-#define EPI_MONITOR_PAR_MAX_WAVES 2       // use the scan-free grid (ekf_monitor_par) while the batch has at most that many waves per SIMD
+#define EPI_MONITOR_PAR_MAX_WAVES 1       // use the scan-free grid (ekf_monitor_par) while the batch has at most that many waves per SIMD
 #endif
     if (ka.L == 21 && (long)mb <= (long)EPI_MONITOR_PAR_MAX_WAVES * simd_count(dev)) {
         constexpr int D = 8;
@@ -1220,8 +1224,15 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
         }
         if constexpr (M == 6 && GENERIC) {
             if (ka.hex && !done) {  // six lanes per chain, ten chains per wavefront (ekf_hex.hpp)
-                if (ka.blk == kHG) hipLaunchKernelGGL((ekf_fwd_hex<FLIP, kHG>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
-                else hipLaunchKernelGGL((ekf_fwd_hex<FLIP, 0>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                const unsigned hblocks = (unsigned)((ka.B + kHG - 1) / kHG);
+                const bool solo = (long)hblocks <= (long)simd_count(L.dev);   // every wave can have a SIMD of its own: keep it that way
+                if (ka.blk == kHG) {
+                    if (solo) hipLaunchKernelGGL((ekf_fwd_hex<FLIP, kHG, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                    else hipLaunchKernelGGL((ekf_fwd_hex<FLIP, kHG, 0>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                } else {
+                    if (solo) hipLaunchKernelGGL((ekf_fwd_hex<FLIP, 0, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                    else hipLaunchKernelGGL((ekf_fwd_hex<FLIP, 0, 0>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                }
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 done = true;
             }
@@ -1301,7 +1312,8 @@ static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st)
     // x extent rounded up to a multiple of 8: the kernel re-orders its tiles so that every XCD gets a contiguous eighth per step
     unsigned tiles = (unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>());
     if (ka.only && tiles > 8u) tiles = 8u;      // the second pass of exact_nonfinite walks the list of marked chains (see eks_pinv)
-    hipLaunchKernelGGL((eks_pinv<M>), dim3(tiles >= 8u ? ((tiles + 7u) & ~7u) : tiles, (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
+    if (ka.only) hipLaunchKernelGGL((eks_pinv<M, 1>), dim3(tiles >= 8u ? ((tiles + 7u) & ~7u) : tiles, (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
+    else hipLaunchKernelGGL((eks_pinv<M, 0>), dim3(tiles >= 8u ? ((tiles + 7u) & ~7u) : tiles, (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
     return hipGetLastError();
 }
 
@@ -1336,8 +1348,15 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
         }
         if constexpr (M == 6 && GENERIC) {
             if (ka.hex && !done) {
-                if (ka.blk == kHG) hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
-                else hipLaunchKernelGGL((eks_bwd_hex<FLIP, 0>), dim3((unsigned)((ka.B + kHG - 1) / kHG)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                const unsigned hblocks = (unsigned)((ka.B + kHG - 1) / kHG);
+                const bool pf = (long)hblocks <= (long)simd_count(L.dev);      // one wave per SIMD: prefetch; beyond: two waves per SIMD
+                if (ka.blk == kHG) {
+                    if (pf) hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                    else hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG, 0>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                } else {
+                    if (pf) hipLaunchKernelGGL((eks_bwd_hex<FLIP, 0, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                    else hipLaunchKernelGGL((eks_bwd_hex<FLIP, 0, 0>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                }
                 done = true;
             }
         }
@@ -1500,6 +1519,68 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
     const bool tp = ka.mon_hoist && !ka.stor && T >= 128 && L.time_pipe >= 0 &&
                     (L.time_pipe == 1 || (!ka.wave && fwd_waves * 4 <= (long)simd_count(L.dev) * 3));
     bool helper_busy = false;
+    // Pipelined in REVERSE time (round 5, the hex shape): the smoother consumes X = pinv(P(k+1|k)) from the last day backwards, so
+    // only the pinv grid of the LAST days has to stand between the forward kernel and the smoother; the grids of the earlier days
+    // run on the helper stream beside the smoother's first launches, and the smoother is cut where they end (the hand-over rows of
+    // the horizon / observed-days split).  Beside the FORWARD kernel a pinv grid takes exactly what it saves (both want the vector
+    // unit: forward segments 1.07 -> 1.50 ms); the smoother of this shape waits on memory most of the time.
+#ifndef EPI_REVERSE_PIPE
+#define EPI_REVERSE_PIPE 1
+#endif
+    const bool rp = EPI_REVERSE_PIPE && !tp && ka.hex && ka.mon_hoist && T >= 128 && L.time_pipe >= 0;
+    if (rp) {
+        if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
+        if ((e = fork(st, h->stream)) != hipSuccess) return e;
+        helper_busy = true;
+        // smoother steps k = T-2 ... 0 in segments [hi, lo], descending: the horizon first when there is a scoring tail, the rest in
+        // three parts; segment s needs X of filter steps lo+1 ... hi+1
+        int seg_hi[8], seg_lo[8], ns = 0, tail_seg = -1;
+        int top = T - 2;
+#ifndef EPI_RP_PARTS
+#define EPI_RP_PARTS 3
+#endif
+#ifndef EPI_RP_FIRST
+#define EPI_RP_FIRST 0            // > 0: a first segment of that many days ahead of everything (probe)
+#endif
+        if (EPI_RP_FIRST > 0 && L.tail && L.tail->t_hist >= 1 && T - 2 - EPI_RP_FIRST > L.tail->t_hist) {
+            seg_hi[ns] = top; seg_lo[ns] = top - EPI_RP_FIRST + 1; ns++;
+            top -= EPI_RP_FIRST;
+        }
+        if (L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2) {
+            seg_hi[ns] = top; seg_lo[ns] = L.tail->t_hist; tail_seg = ns; ns++;
+            top = L.tail->t_hist - 1;
+        }
+        const int parts = (top + 1 >= 96) ? EPI_RP_PARTS : 1;
+        for (int q = 0; q < parts; q++) {
+            const int lo = (int)((long)(top + 1) * (parts - 1 - q) / parts);
+            seg_hi[ns] = top; seg_lo[ns] = lo; ns++;
+            top = lo - 1;
+        }
+        hipEvent_t ev_pinv[8];
+        for (int sgm = 0; sgm < ns; sgm++) {
+            const int j_lo = seg_lo[sgm] + 1, j_hi = seg_hi[sgm] + 1;
+            hipStream_t ps = sgm == 0 ? st : h->stream;
+            if ((e = enqueue_pinv<M>(ka, FLIP ? (T - 1 - j_hi) : (j_lo - 1), j_hi - j_lo + 1, ps)) != hipSuccess) return e;
+            if (sgm > 0) {
+                ev_pinv[sgm] = h->ev[ne++];
+                if ((e = hipEventRecord(ev_pinv[sgm], h->stream)) != hipSuccess) return e;
+            }
+        }
+        for (int sgm = 0; sgm < ns; sgm++) {
+            if (sgm > 0 && (e = hipStreamWaitEvent(st, ev_pinv[sgm], 0)) != hipSuccess) return e;
+            KArgs kb = ka;
+            kb.bk_from = seg_hi[sgm]; kb.bk_to = seg_lo[sgm];
+            if ((e = enqueue_bwd<M, FLIP, GENERIC>(kb, L, st)) != hipSuccess) return e;
+            if (sgm == tail_seg) {              // the horizon's u_opt_smooth is final: scoring + Pareto filter behind the helper's pinv grids
+                if ((e = fork(st, h->stream)) != hipSuccess) return e;
+                if ((e = enqueue_tail(ka, *L.tail, h->stream)) != hipSuccess) return e;
+            }
+        }
+        if (L.tail && tail_seg < 0 && (e = enqueue_tail(ka, *L.tail, st)) != hipSuccess) return e;
+        if (ka.rho || ka.f.rho) {
+            if ((e = launch_monitor<FLIP>(ka, L.dev, h->stream)) != hipSuccess) return e;
+        }
+    } else {
     if (tp) {
         for (int sg = 0; sg < kTimeSeg; sg++) {
             KArgs kc = ka;
@@ -1536,6 +1617,7 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
     } else {
         if ((e = enqueue_bwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         if (L.tail && (e = enqueue_tail(ka, *L.tail, st)) != hipSuccess) return e;
+    }
     }
     if (helper_busy) e = fork(h->stream, st);
     if constexpr (GENERIC) {
