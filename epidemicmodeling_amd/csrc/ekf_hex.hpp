@@ -37,12 +37,23 @@ constexpr int kHN = 12;         // doubles per chain in an NPI row
 
 typedef double hx_d2 __attribute__((ext_vector_type(2)));
 
+// Addressing windows.  Day offsets travel in the buffer instructions' 32-bit SCALAR offset: an array's descriptor then names a
+// fixed base and does not change from day to day, where a descriptor per array and day costs the scalar unit ten instructions
+// each (a 64-bit base sum, the mask, the moves into an aligned quad; the kernels also ran out of scalar registers over it and
+// kept their pointers in VGPR lanes) -- and a lone wave pays four cycles for EVERY instruction it issues (9 375-chain shard:
+// 2.72 -> 2.62 ms per pass with the empty-descriptor change that came with it).  The hardware's bounds check includes the scalar
+// offset (out of range: offset >= num_records - soffset), so the record count cannot clip a day's slice any more: every live
+// access is in range by construction, the count (just below 2 GiB, 0 for an output that was not selected) only has to drop
+// the lanes that must not store, which carry bit 31 in their offset; rows beyond n_npi are predicated by hand.  A window is
+// the run of days whose offsets fit: the kernels move every array's base at its start (HexWin; one window for 520 days of up
+// to 14 000 chains).
+constexpr unsigned kHexDead = 0x80000000u, kHexRecords = 0x7FFFFFF8u;
 struct HexLane {
     int g, j, c;                // group (chain of the wavefront), column owned, chain
     bool live;                  // the chain exists: this lane stores
-    unsigned dead;              // added to every store offset: 0, or 3 GiB for a lane that must not store -- beyond any slice
-                                // (a slice is < 2.5 GB: rows * B * 8 with B <= 2^23), so the descriptor's bounds check drops
-                                // the store and no store needs an EXEC-mask branch around it
+    unsigned dead;              // OR-ed into every store offset: 0, or bit 31 for a lane that must not store -- beyond the record
+                                // count, so the descriptor's bounds check drops the store and no store needs an EXEC-mask
+                                // branch around it
 };
 EPI_DEV HexLane hx_lane(const KArgs &a)
 {
@@ -54,9 +65,9 @@ EPI_DEV HexLane hx_lane(const KArgs &a)
     h.live = h.g < kHG && c < a.c0 + a.cn;
     h.c = h.live ? c : a.c0 + a.cn - 1;           // idle groups mirror the last chain: what they compute is dropped
 #ifdef EPI_HEX_NOSTORE           // timing probe: no lane stores anything (results are wrong)
-    h.dead = 0xC0000000u;
+    h.dead = kHexDead;
 #else
-    h.dead = h.live ? 0u : 0xC0000000u;
+    h.dead = h.live ? 0u : kHexDead;
 #endif
     return h;
 }
@@ -164,46 +175,99 @@ EPI_DEV void hx_load_prm(QPrm &p, HexNpi &n, const KArgs &a, int B, const HexLan
     for (int k = 0; k < kNpi; k++) n.ga[k] = p.gamma * g(EPI_PRM_A + k);
 }
 // u(k, t) for my two NPIs (rows beyond n_npi read 0.0 through the descriptor's bounds check, see load_u)
-EPI_DEV void hx_load_u(const KArgs &a, int t, int su, int j, double (&u2)[2])
+EPI_DEV void hx_load_u_at(const double *u, const KArgs &a, unsigned byte_off, int su, int j, double (&u2)[2])
 {
     const unsigned rowb = (unsigned)a.Su * 8u, voff = (unsigned)su * 8u + (unsigned)j * rowb;
-    const rsrc_t r = mk_rsrc(a.u + (size_t)t * a.n_npi * a.Su, (unsigned)a.n_npi * rowb);
-    u2[0] = bld(r, voff, 0u);
-    u2[1] = bld(r, voff, 6u * rowb);
+    const rsrc_t r = mk_rsrc(u, kHexRecords);
+    u2[0] = bld(r, (j < a.n_npi) ? voff : kHexDead, byte_off);
+    u2[1] = bld(r, (j + 6 < a.n_npi) ? voff : kHexDead, byte_off + 6u * rowb);
+}
+EPI_DEV void hx_load_u(const double *u, const KArgs &a, int t, int su, int j, double (&u2)[2])
+{
+    hx_load_u_at(u, a, (unsigned)t * a.n_npi * a.Su * 8u, su, j, u2);
 }
 // Addressing of the chain-blocked arrays (see Lay).  BLK > 0: the layout's lane_block is that compile-time constant (10 = one
 // block per wavefront, what the host chooses for this shape): the row pitch is 80 bytes, every row offset folds into the
 // instruction's 12-bit immediate and no scalar register holds one (the kernels run out of them otherwise and re-load their
 // arguments every day).  BLK = 0: any layout, row offsets in SGPRs.
-// Time slice t of an output array -- or, for an output the caller did not select (dst == NULL), an EMPTY descriptor: every
-// store through it is dropped by the bounds check, and no store sits behind a branch (the waits the compiler places for the
-// loads of a step count the stores issued since, which it can only do in straight-line code).
+// An output the caller did not select (dst == NULL) gets an EMPTY descriptor: every store through it is dropped by the bounds
+// check, and no store sits behind a branch (the waits the compiler places for the loads of a step count the stores issued
+// since, which it can only do in straight-line code).  Only the RECORD COUNT depends on dst: a selected base address as well
+// makes the compiler branch around the address arithmetic of every array every day.
+EPI_DEV rsrc_t hx_rsrc(const void *dst) { return mk_rsrc(dst, dst ? kHexRecords : 0u); }
+// The day of an array -- counted from the window's first day -- is named either by its index t or (the smoother's loop, see
+// HexDay) by its byte offset.
+struct HexAt { unsigned off; };
 template <int BLK>
-EPI_DEV rsrc_t hx_slice(const double *dst, int t, unsigned rows, const Lay &l, unsigned &voff, unsigned &rowb)
+EPI_DEV rsrc_t hx_slice(const double *dst, HexAt at, unsigned rows, const Lay &l, unsigned &voff, unsigned &rowb)
 {
     const unsigned blk = BLK ? (unsigned)BLK : l.blk;
     rowb = blk * 8u;
     voff = (l.cb * rows * blk + l.cr) * 8u;
-    return mk_rsrc(dst ? dst + (size_t)t * rows * l.bp : nullptr, dst ? rows * l.bp * 8u : 0u);
+    return hx_rsrc(dst);
 }
-template <int BLK> EPI_DEV void hx_st(rsrc_t r, unsigned vo, unsigned row, unsigned rowb, double v)
-{
-    if (BLK) hst(r, vo + row * ((unsigned)BLK * 8u), 0u, v); else hst(r, vo, row * rowb, v);
-}
-template <int BLK> EPI_DEV double hx_ld(rsrc_t r, unsigned vo, unsigned row, unsigned rowb)
-{
-    return BLK ? bld_s(r, vo + row * ((unsigned)BLK * 8u), 0u) : bld_s(r, vo, row * rowb);
-}
+EPI_DEV unsigned hx_soff(HexAt at, unsigned, const Lay &) { return at.off; }
+EPI_DEV unsigned hx_soff(int t, unsigned rows, const Lay &l) { return (unsigned)t * rows * l.bp * 8u; }
 template <int BLK>
-EPI_DEV void hx_store_u(double *__restrict__ dst, const KArgs &a, int t, const Lay &l, const HexLane &h, const double (&u2)[2])
+EPI_DEV rsrc_t hx_slice(const double *dst, int t, unsigned rows, const Lay &l, unsigned &voff, unsigned &rowb)
+{
+    return hx_slice<BLK>(dst, HexAt{0u}, rows, l, voff, rowb);
+}
+// Byte offsets of ONE day (relative to the window's base) in the arrays of each row count -- one-row arrays of doubles (words:
+// half of it), 6, 21 (packed X), 36 and n_npi rows, and the classic [T][n_npi][Su] control series -- carried from day to day by
+// additions: the smoother's loop, whose day indices the compiler does not strength-reduce (its prefetch index may be -1).
+struct HexDay { unsigned o1, o6, o21, o36, on, ou; };
+struct HexDayStride { unsigned s1, s6, s21, s36, sn, su; };
+EPI_DEV HexDayStride hx_day_stride(const KArgs &a, const Lay &l)
+{
+    HexDayStride s;
+    s.s1 = l.bp * 8u; s.s6 = l.bp * 48u; s.s21 = l.bp * 168u; s.s36 = l.bp * 288u;
+    s.sn = l.bp * 8u * (unsigned)a.n_npi; s.su = (unsigned)a.n_npi * (unsigned)a.Su * 8u;
+    return s;
+}
+// days per addressing window: even (the loops alternate two input sets and a window must end on the second), and three days of
+// the widest array short of the record count (the prefetch reaches one day beyond the window on either side)
+EPI_DEV int hx_window(const KArgs &a, const Lay &l)
+{
+    if (a.hexw >= 2) return a.hexw & ~1;
+    const unsigned s36 = l.bp * 288u, su = (unsigned)a.n_npi * (unsigned)a.Su * 8u;
+    const int w = (int)(kHexRecords / (s36 > su ? s36 : su)) - 3;
+    return w < 2 ? 2 : (w & ~1);
+}
+template <class P> EPI_DEV P *hx_rebase(P *p, int tw, size_t elems_per_day) { return p ? p + (size_t)tw * elems_per_day : nullptr; }
+EPI_DEV HexDay hx_day(const HexDayStride &s, int t)
+{
+    HexDay d;
+    const unsigned tt = (unsigned)t;
+    d.o1 = tt * s.s1; d.o6 = tt * s.s6; d.o21 = tt * s.s21; d.o36 = tt * s.s36; d.on = tt * s.sn; d.ou = tt * s.su;
+    return d;
+}
+template <int DIR> EPI_DEV HexDay hx_day_next(const HexDay &d, const HexDayStride &s)      // day t + DIR
+{
+    HexDay n;
+    if (DIR > 0) { n.o1 = d.o1 + s.s1; n.o6 = d.o6 + s.s6; n.o21 = d.o21 + s.s21; n.o36 = d.o36 + s.s36; n.on = d.on + s.sn; n.ou = d.ou + s.su; }
+    else { n.o1 = d.o1 - s.s1; n.o6 = d.o6 - s.s6; n.o21 = d.o21 - s.s21; n.o36 = d.o36 - s.s36; n.on = d.on - s.sn; n.ou = d.ou - s.su; }
+    return n;
+}
+template <int BLK> EPI_DEV void hx_st(rsrc_t r, unsigned vo, unsigned row, unsigned rowb, double v, unsigned so)
+{
+    if (BLK) hst(r, vo + row * ((unsigned)BLK * 8u), so, v); else hst(r, vo, so + row * rowb, v);
+}
+template <int BLK> EPI_DEV double hx_ld(rsrc_t r, unsigned vo, unsigned row, unsigned rowb, unsigned so)
+{
+    return BLK ? bld_s(r, vo + row * ((unsigned)BLK * 8u), so) : bld_s(r, vo, so + row * rowb);
+}
+template <int BLK, class TT>
+EPI_DEV void hx_store_u(double *__restrict__ dst, const KArgs &a, TT t, const Lay &l, const HexLane &h, const double (&u2)[2])
 {
     unsigned voff, rowb;
     const rsrc_t r = hx_slice<BLK>(dst, t, (unsigned)a.n_npi, l, voff, rowb);
+    const unsigned so = hx_soff(t, (unsigned)a.n_npi, l);
     const unsigned vo = (voff + (unsigned)h.j * rowb) | h.dead;
     // rows beyond n_npi lie beyond the slice (its last block's rows at the latest): dropped by the bounds check -- but a row
     // k >= n_npi of an EARLIER block would land in the next block's rows, so those lanes are sent out of range as well
-    hx_st<BLK>(r, (h.j < a.n_npi) ? vo : 0xC0000000u, 0u, rowb, u2[0]);
-    hx_st<BLK>(r, (h.j + 6 < a.n_npi) ? vo : 0xC0000000u, 6u, rowb, u2[1]);
+    hx_st<BLK>(r, (h.j < a.n_npi) ? vo : kHexDead, 0u, rowb, u2[0], so);
+    hx_st<BLK>(r, (h.j + 6 < a.n_npi) ? vo : kHexDead, 6u, rowb, u2[1], so);
 }
 // bang-bang substitution of my NaN controls (OptControlled.m:49-58) and my slope-term contributions (:107-114)
 EPI_DEV void hx_resolve(const QPrm &p, const HexNpi &n, const ModelFlags &mf, double s6, const double (&u2)[2], double (&ur)[2],
@@ -281,61 +345,69 @@ EPI_DEV void hx_mul_A(const double (&A)[36], const double (&v)[6], double (&o)[6
 }
 
 // vector arrays (6 rows): lane j stores row j
-template <int BLK>
-EPI_DEV void hx_store_elem(double *__restrict__ dst, int t, const Lay &l, const HexLane &h, double v)
+template <int BLK, class TT>
+EPI_DEV void hx_store_elem(double *__restrict__ dst, TT t, const Lay &l, const HexLane &h, double v)
 {
     unsigned voff, rowb;
     const rsrc_t r = hx_slice<BLK>(dst, t, 6, l, voff, rowb);
-    hst(r, (voff + (unsigned)h.j * rowb) | h.dead, 0u, v);
+    hst(r, (voff + (unsigned)h.j * rowb) | h.dead, hx_soff(t, 6, l), v);
 }
 // one-row arrays ([T][nblk * blk] doubles: innovations): the six lanes of a chain store the same word
 EPI_DEV void hx_store_scalar(double *__restrict__ dst, int t, const Lay &l, const HexLane &h, double v)
 {
-    hst(mk_rsrc(dst ? dst + (size_t)t * l.bp : nullptr, dst ? l.bp * 8u : 0u), (l.c * 8u) | h.dead, 0u, v);
+    hst(hx_rsrc(dst), (l.c * 8u) | h.dead, (unsigned)t * l.bp * 8u, v);
+}
+EPI_DEV void hx_store_word(int32_t *__restrict__ dst, HexAt at, const Lay &l, const HexLane &h, int32_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(v, hx_rsrc(dst), (l.c * 4u) | h.dead, at.off, 0);
 }
 EPI_DEV void hx_store_word(int32_t *__restrict__ dst, int t, const Lay &l, const HexLane &h, int32_t v)
 {
-    __builtin_amdgcn_raw_buffer_store_b32(v, mk_rsrc(dst ? dst + (size_t)t * l.bp : nullptr, dst ? l.bp * 4u : 0u), (l.c * 4u) | h.dead, 0u, 0);
+    hx_store_word(dst, HexAt{(unsigned)t * l.bp * 4u}, l, h, v);
 }
-template <int BLK>
-EPI_DEV void hx_load_vec(const double *__restrict__ src, int t, const Lay &l, double (&v)[6])
+EPI_DEV int32_t hx_load_word(const int32_t *__restrict__ src, HexAt at, const Lay &l)
+{
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(mk_rsrc(src, kHexRecords), l.c * 4u, at.off, 0);
+}
+template <int BLK, class TT>
+EPI_DEV void hx_load_vec(const double *__restrict__ src, TT t, const Lay &l, double (&v)[6])
 {
     unsigned voff, rowb;
     const rsrc_t r = hx_slice<BLK>(src, t, 6, l, voff, rowb);
 #pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = hx_ld<BLK>(r, voff, (unsigned)i, rowb);
+    for (int i = 0; i < 6; i++) v[i] = hx_ld<BLK>(r, voff, (unsigned)i, rowb, hx_soff(t, 6, l));
 }
 // my element of a 6-row vector array
-template <int BLK>
-EPI_DEV double hx_load_elem(const double *__restrict__ src, int t, const Lay &l, int j)
+template <int BLK, class TT>
+EPI_DEV double hx_load_elem(const double *__restrict__ src, TT t, const Lay &l, int j)
 {
     unsigned voff, rowb;
     const rsrc_t r = hx_slice<BLK>(src, t, 6, l, voff, rowb);
-    return bld_s(r, voff + (unsigned)j * rowb, 0u);
+    return bld_s(r, voff + (unsigned)j * rowb, hx_soff(t, 6, l));
 }
 // my column of a SYMMETRIC 6 x 6 array stored with all 36 rows (row e = i + 6 j): element (i, j) of my column goes to the
 // position of element (j, i) -- the same bits (the lane that owns column i stores the same value at (i, j)) -- so that one
 // store instruction covers rows 6 i + (0..5) of the wavefront's ten chains: 480 contiguous bytes when the layout block is
 // the wavefront's ten chains, instead of six 80-byte pieces 480 bytes apart (partial cache lines: measured 2.9 instead of
 // 1.2 ms for the forward kernel of the 9 375-chain shard)
-template <int BLK>
-EPI_DEV void hx_store_col(double *__restrict__ dst, int t, const Lay &l, const HexLane &h, const double (&v)[6])
+template <int BLK, class TT>
+EPI_DEV void hx_store_col(double *__restrict__ dst, TT t, const Lay &l, const HexLane &h, const double (&v)[6])
 {
     unsigned voff, rowb;
     const rsrc_t r = hx_slice<BLK>(dst, t, 36, l, voff, rowb);
     const unsigned vo = (voff + (unsigned)h.j * rowb) | h.dead;
 #pragma unroll
-    for (int i = 0; i < 6; i++) hx_st<BLK>(r, vo, (unsigned)(6 * i), rowb, v[i]);
+    for (int i = 0; i < 6; i++) hx_st<BLK>(r, vo, (unsigned)(6 * i), rowb, v[i], hx_soff(t, 36, l));
 }
 // my column of a symmetric 6 x 6 array that hx_store_col wrote (all 36 rows): element (i, j) from the position of (j, i)
-template <int BLK>
-EPI_DEV void hx_load_col(const double *__restrict__ src, int t, const Lay &l, int j, double (&v)[6])
+template <int BLK, class TT>
+EPI_DEV void hx_load_col(const double *__restrict__ src, TT t, const Lay &l, int j, double (&v)[6])
 {
     unsigned voff, rowb;
     const rsrc_t r = hx_slice<BLK>(src, t, 36, l, voff, rowb);
     const unsigned vo = voff + (unsigned)j * rowb;
 #pragma unroll
-    for (int i = 0; i < 6; i++) v[i] = hx_ld<BLK>(r, vo, (unsigned)(6 * i), rowb);
+    for (int i = 0; i < 6; i++) v[i] = hx_ld<BLK>(r, vo, (unsigned)(6 * i), rowb, hx_soff(t, 36, l));
 }
 
 // ---------------------------------------------------------------------------
@@ -348,7 +420,7 @@ struct HexFwdIn { double x, r, u[2]; };
 // there, and the launch ends with the slowest pair (forward stage of the 9 375-chain shard 1.23-1.28 -> 1.02-1.03 ms; the first
 // version of the kernel, bound by its stores, did not care).  SOLO = 0 for grids beyond one wave per SIMD.
 template <int FLIP, int BLK, int SOLO = 0>
-__global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *__restrict__ dense_flag)
+__global__ __launch_bounds__(kWave, SOLO ? 1 : 2) void ekf_fwd_hex(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
     __shared__ __attribute__((aligned(16))) double tA[kHGp * kHT], tB[kHGp * kHT], tC[kHGp * kHT], tD[kHGp * kHT];
@@ -383,10 +455,17 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *_
 
     // time segments: see ekf_fwd_sym
     const int k_begin = a.k_begin, k_end = (a.k_end > 0 && a.k_end < T) ? a.k_end : T;
-    if (k_begin > 0) {
-        hx_load_vec<BLK>(a.S_MINUS, tpos<FLIP>(k_begin, T), lay, sk_minus);
-        hx_load_col<BLK>(a.P_MINUS, tpos<FLIP>(k_begin, T), lay, j, Pc);
-    }
+    // the arrays of the current addressing window (see kHexDead): bases at its first day `tw`, days counted from there
+    struct { double *S_MINUS, *P_MINUS, *S_PLUS, *P_PLUS, *K_GAIN, *innovations, *u_opt; const double *u; } w;
+    int tw = 0;
+    auto rebase = [&](int t0) __attribute__((always_inline)) {
+        tw = t0;
+        const size_t bp = lay.bp;
+        w.S_MINUS = hx_rebase(a.S_MINUS, t0, 6 * bp); w.S_PLUS = hx_rebase(a.S_PLUS, t0, 6 * bp); w.K_GAIN = hx_rebase(a.K_GAIN, t0, 6 * bp);
+        w.P_MINUS = hx_rebase(a.P_MINUS, t0, 36 * bp); w.P_PLUS = hx_rebase(a.P_PLUS, t0, 36 * bp);
+        w.innovations = hx_rebase(a.innovations, t0, bp); w.u_opt = hx_rebase(a.u_opt, t0, (size_t)a.n_npi * bp);
+        w.u = hx_rebase(a.u, t0, (size_t)a.n_npi * a.Su);
+    };
     const unsigned voff_x = (unsigned)sx * 8u;
     // the inputs of a day are requested one day ahead into one of two register sets used alternately (the loop body exists
     // twice): nothing is copied at the end of a day, so no day ends by waiting for its own stores to drain
@@ -394,15 +473,15 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *_
         const int tn = tpos<FLIP>(k, T);
         d.x = ldg(a.x + (size_t)tn * a.Sx, voff_x);
         d.r = ldg(a.R_series + (size_t)k * a.Sx, voff_x);                 // R_v is not time-flipped (Backward*.m:27)
-        hx_load_u(a, tn, su, j, d.u);
+        hx_load_u(w.u, a, tn - tw, su, j, d.u);
     };
     auto day = [&](int k, const HexFwdIn &cur) __attribute__((always_inline)) {
-        const int t = tpos<FLIP>(k, T);
+        const int t = tpos<FLIP>(k, T) - tw;                                 // day of the window
         const double Rk = cur.r, xk = cur.x;
         const double (&u_in)[2] = cur.u;
 
-        hx_store_elem<BLK>(a.S_MINUS, t, lay, h, hx_pick(sk_minus, j));          // :100-101
-        hx_store_col<BLK>(a.P_MINUS, t, lay, h, Pc);
+        hx_store_elem<BLK>(w.S_MINUS, t, lay, h, hx_pick(sk_minus, j));          // :100-101
+        hx_store_col<BLK>(w.P_MINUS, t, lay, h, Pc);
 
         double C[M];
         obs_jacobian<M>(a.mf, sk_minus, C);                                 // :115, C(4:6) == 0
@@ -469,16 +548,16 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *_
 #pragma unroll
             for (int i = 0; i < M; i++) { sk_plus[i] = sk_minus[i]; Ppc[i] = Pc[i]; }
         }
-        hx_store_elem<BLK>(a.K_GAIN, t, lay, h, Kj);
-        hx_store_scalar(a.innovations, t, lay, h, innov);
+        hx_store_elem<BLK>(w.K_GAIN, t, lay, h, Kj);
+        hx_store_scalar(w.innovations, t, lay, h, innov);
         state_hard_margins<M>(p, sk_plus);                                  // :141
-        hx_store_elem<BLK>(a.S_PLUS, t, lay, h, hx_pick(sk_plus, j));            // :167-169
-        hx_store_col<BLK>(a.P_PLUS, t, lay, h, Ppc);
+        hx_store_elem<BLK>(w.S_PLUS, t, lay, h, hx_pick(sk_plus, j));            // :167-169
+        hx_store_col<BLK>(w.P_PLUS, t, lay, h, Ppc);
 
         // s(k+1|k) = NlinStateUpdate(u, s+), A = StateJacobians(u, s+)  :155-157
         double u_app[2], tm[2], d2[2], d[kNpi];
         hx_resolve(p, np, a.mf, sk_plus[5], u_in, u_app, tm);
-        hx_store_u<BLK>(a.u_opt, a, t, lay, h, u_app);
+        hx_store_u<BLK>(w.u_opt, a, t, lay, h, u_app);
         d2[0] = np.umax[0] - u_app[0];
         d2[1] = np.umax[1] - u_app[1];
         hx_gather12(vDg, j, d2, d);
@@ -506,25 +585,43 @@ __global__ __launch_bounds__(kWave) void ekf_fwd_hex(const KArgs a, const int *_
     };
     {
         HexFwdIn bufA, bufB;
+        const int W = hx_window(a, lay);
         int k = k_begin;
-        if (k < k_end) fetch(k, bufA);
-        // Everything loaded so far has landed before the loop is entered.  Otherwise the loop inherits the prologue's pending
-        // loads: the compiler's wait-count pass merges "requested just now, nothing issued since" (from here) with "requested a
-        // day ago, eighteen stores issued since" (from the back edge) into the stricter of the two, and EVERY day then begins
-        // by waiting until all but its own four new requests have drained -- i.e. for the previous day's stores.
-        __builtin_amdgcn_s_waitcnt(0);
-        while (k < k_end) {
-            if (k + 1 < T) fetch(k + 1, bufB);
-            day(k, bufA);
-            if (++k >= k_end) break;
-            if (k + 1 < T) fetch(k + 1, bufA);
-            day(k, bufB);
-            ++k;
+        bool first = true;
+        while (k < k_end) {                      // one addressing window per pass: filter steps [k, w1)
+            const int w1 = (k_end - k > W) ? k + W : k_end;
+            // its earliest day -- the day after its last step included: the inputs of that one are requested from here
+            rebase(FLIP ? tpos<FLIP>(w1 < T ? w1 : T - 1, T) : k);
+            if (first) {
+                if (k_begin > 0) {
+                    hx_load_vec<BLK>(w.S_MINUS, tpos<FLIP>(k_begin, T) - tw, lay, sk_minus);
+                    hx_load_col<BLK>(w.P_MINUS, tpos<FLIP>(k_begin, T) - tw, lay, j, Pc);
+                }
+                fetch(k, bufA);
+                // Everything loaded so far has landed before the loop is entered.  Otherwise the loop inherits the prologue's
+                // pending loads: the compiler's wait-count pass merges "requested just now, nothing issued since" (from here)
+                // with "requested a day ago, eighteen stores issued since" (from the back edge) into the stricter of the two,
+                // and EVERY day then begins by waiting until all but its own four new requests have drained -- i.e. for the
+                // previous day's stores.
+                __builtin_amdgcn_s_waitcnt(0);
+                first = false;
+            }
+            // the inputs of a day are requested one day ahead into one of two register sets used alternately (the loop body
+            // exists twice); a window that is not the last has an even number of days and hands bufA to the next
+            while (k < w1) {
+                if (k + 1 < T) fetch(k + 1, bufB);
+                day(k, bufA);
+                if (++k >= w1) break;
+                if (k + 1 < T) fetch(k + 1, bufA);
+                day(k, bufB);
+                ++k;
+            }
         }
     }
     if (k_end < T) {       // hand-over to the next time segment
-        hx_store_elem<BLK>(a.S_MINUS, tpos<FLIP>(k_end, T), lay, h, hx_pick(sk_minus, j));
-        hx_store_col<BLK>(a.P_MINUS, tpos<FLIP>(k_end, T), lay, h, Pc);
+        rebase(tpos<FLIP>(k_end, T));
+        hx_store_elem<BLK>(w.S_MINUS, 0, lay, h, hx_pick(sk_minus, j));
+        hx_store_col<BLK>(w.P_MINUS, 0, lay, h, Pc);
     }
 }
 
@@ -558,7 +655,7 @@ struct HexBwdIn { double Sp[6], Sm1[6], u[2], Ppc[6], Pm1c[6], X[21]; int rk; };
 // for launches of at most one wave per SIMD; PF = 0: requested at the start of the step (242 registers, no accumulation
 // registers: TWO waves per SIMD, which hide each other's memory latency) -- for larger launches.
 template <int FLIP, int BLK, int PF = 1>
-__global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *__restrict__ dense_flag)
+__global__ __launch_bounds__(kWave, PF ? 1 : 2) void eks_bwd_hex(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
     __shared__ __attribute__((aligned(16))) double tJ[kHGp * kHT], tB[kHGp * kHT], tC[kHGp * kHT];
@@ -599,7 +696,24 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
     const size_t hp = (size_t)a.hand_pitch;
     int st_guard = 0, st_cap = 0, min_rank = M;
     double Ss[M], Psc[M];
-    const int tT = tpos<FLIP>(T - 1, T);
+    // the arrays of the current addressing window (see kHexDead): bases at its first day `tw`, days counted from there
+    struct {
+        const double *S_PLUS, *P_PLUS, *X, *S_MINUS, *P_MINUS, *u;
+        const int32_t *rankbuf;
+        double *S_SMOOTH, *P_SMOOTH, *u_opt_smooth;
+        int32_t *pinv_rank;
+    } w;
+    int tw = 0;
+    auto rebase = [&](int t0) __attribute__((always_inline)) {
+        tw = t0;
+        const size_t bp = lay.bp;
+        w.S_PLUS = hx_rebase(a.S_PLUS, t0, 6 * bp); w.S_MINUS = hx_rebase(a.S_MINUS, t0, 6 * bp); w.S_SMOOTH = hx_rebase(a.S_SMOOTH, t0, 6 * bp);
+        w.P_PLUS = hx_rebase(a.P_PLUS, t0, 36 * bp); w.P_MINUS = hx_rebase(a.P_MINUS, t0, 36 * bp); w.P_SMOOTH = hx_rebase(a.P_SMOOTH, t0, 36 * bp);
+        w.X = hx_rebase(a.X, t0, 21 * bp);
+        w.rankbuf = hx_rebase(a.rankbuf, t0, bp); w.pinv_rank = hx_rebase(a.pinv_rank, t0, bp);
+        w.u_opt_smooth = hx_rebase(a.u_opt_smooth, t0, (size_t)a.n_npi * bp);
+        w.u = hx_rebase(a.u, t0, (size_t)a.n_npi * a.Su);
+    };
     if (k_from < T - 2) {
 #pragma unroll
         for (int i = 0; i < M; i++) {
@@ -608,69 +722,71 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
         }
         const int word = a.hand_i[c];
         st_guard = word & 1; st_cap = (word >> 1) & 1; min_rank = word >> 8;
-    } else {
-        // terminal conditions GenericEKF.m:189-202 (Ps_final symmetric in values and NaN pattern: ekf_precheck)
-        hx_load_vec<BLK>(a.S_PLUS, tT, lay, Ss);
+    }
+    // terminal conditions GenericEKF.m:189-202 (Ps_final symmetric in values and NaN pattern: ekf_precheck); the last day lies
+    // in the first window
+    auto terminal = [&]() __attribute__((always_inline)) {
+        const int tT = tpos<FLIP>(T - 1, T) - tw;
+        hx_load_vec<BLK>(w.S_PLUS, tT, lay, Ss);
 #pragma unroll
         for (int i = 0; i < M; i++) {
             const double f = a.s_final[(size_t)i * B + c];
             if (!is_nan(f)) Ss[i] = f;
         }
-        hx_load_col<BLK>(a.P_PLUS, tT, lay, j, Psc);
+        hx_load_col<BLK>(w.P_PLUS, tT, lay, j, Psc);
 #pragma unroll
         for (int i = 0; i < M; i++) {
             const int lo = i < j ? i : j, hi = i < j ? j : i;
             const double f = a.Ps_final[(size_t)IXM(lo, hi) * B + c];
             if (!is_nan(f)) Psc[i] = f;
         }
-        hx_store_elem<BLK>(a.S_SMOOTH, tT, lay, h, hx_pick(Ss, j));
-        hx_store_col<BLK>(a.P_SMOOTH, tT, lay, h, Psc);
+        hx_store_elem<BLK>(w.S_SMOOTH, tT, lay, h, hx_pick(Ss, j));
+        hx_store_col<BLK>(w.P_SMOOTH, tT, lay, h, Psc);
         if (a.u_opt_smooth) {
             const double z[2] = {0.0, 0.0};
-            hx_store_u<BLK>(a.u_opt_smooth, a, tT, lay, h, z);                   // column T is never written :95,204
+            hx_store_u<BLK>(w.u_opt_smooth, a, tT, lay, h, z);                   // column T is never written :95,204
         }
-        hx_store_word(a.pinv_rank, tT, lay, h, -1);
-    }
+        hx_store_word(w.pinv_rank, tT, lay, h, -1);
+    };
 
     // everything step k reads is requested one iteration ahead: the stored forward quantities come from HBM
-    auto fetch = [&](int k, HexBwdIn &d) __attribute__((always_inline)) {
-        const int t = tpos<FLIP>(k, T), t1 = tpos<FLIP>(k + 1, T);
+    // (dt: the day of step k, tpos(k); dt1: the day after it in filter order, tpos(k + 1) -- see HexDay)
+    auto fetch = [&](const HexDay &dt, const HexDay &dt1, HexBwdIn &d) __attribute__((always_inline)) {
 #if EPI_HEX_SHARE_LOADS
-        d.Spj = hx_load_elem<BLK>(a.S_PLUS, t, lay, j);
-        hx_load_u(a, t, su, j, d.u);
-        d.rk = a.rankbuf[lay_scalar(t1, lay)];
-        hx_load_col<BLK>(a.P_PLUS, t, lay, j, d.Ppc);
+        d.Spj = hx_load_elem<BLK>(w.S_PLUS, HexAt{dt.o6}, lay, j);
+        hx_load_u_at(w.u, a, dt.ou, su, j, d.u);
+        d.rk = hx_load_word(w.rankbuf, HexAt{dt1.o1 >> 1}, lay);
+        hx_load_col<BLK>(w.P_PLUS, HexAt{dt.o36}, lay, j, d.Ppc);
         {
             unsigned voff, rowb;
-            const rsrc_t r = hx_slice<BLK>(a.X, t1, 21, lay, voff, rowb);  // (garbage where the :211 guard fired, rk < 0: unused)
+            const rsrc_t r = hx_slice<BLK>(w.X, HexAt{dt1.o21}, 21, lay, voff, rowb);  // (garbage where the :211 guard fired, rk < 0: unused)
             const unsigned vo = voff + (unsigned)j * rowb;
 #pragma unroll
-            for (int m = 0; m < 3; m++) d.Xp[m] = hx_ld<BLK>(r, vo, (unsigned)(6 * m), rowb);
-            d.Xp[3] = hx_ld<BLK>(r, voff + (unsigned)(j < 3 ? j : 2) * rowb, 18u, rowb);     // packed entries 18..20 exist for j < 3
+            for (int m = 0; m < 3; m++) d.Xp[m] = hx_ld<BLK>(r, vo, (unsigned)(6 * m), rowb, dt1.o21);
+            d.Xp[3] = hx_ld<BLK>(r, voff + (unsigned)(j < 3 ? j : 2) * rowb, 18u, rowb, dt1.o21);     // packed entries 18..20 exist for j < 3
         }
-        d.Sm1j = hx_load_elem<BLK>(a.S_MINUS, t1, lay, j);
+        d.Sm1j = hx_load_elem<BLK>(w.S_MINUS, HexAt{dt1.o6}, lay, j);
 #if !EPI_HEX_BWD_RECOMPUTE
-        hx_load_col<BLK>(a.P_MINUS, t1, lay, j, d.Pm1c);
+        hx_load_col<BLK>(w.P_MINUS, HexAt{dt1.o36}, lay, j, d.Pm1c);
 #endif
 #else
-        hx_load_vec<BLK>(a.S_PLUS, t, lay, d.Sp);
-        hx_load_u(a, t, su, j, d.u);
-        d.rk = a.rankbuf[lay_scalar(t1, lay)];
-        hx_load_col<BLK>(a.P_PLUS, t, lay, j, d.Ppc);
+        hx_load_vec<BLK>(w.S_PLUS, HexAt{dt.o6}, lay, d.Sp);
+        hx_load_u_at(w.u, a, dt.ou, su, j, d.u);
+        d.rk = hx_load_word(w.rankbuf, HexAt{dt1.o1 >> 1}, lay);
+        hx_load_col<BLK>(w.P_PLUS, HexAt{dt.o36}, lay, j, d.Ppc);
         {
             unsigned voff, rowb;
-            const rsrc_t r = hx_slice<BLK>(a.X, t1, 21, lay, voff, rowb);  // (garbage where the :211 guard fired, rk < 0: unused)
+            const rsrc_t r = hx_slice<BLK>(w.X, HexAt{dt1.o21}, 21, lay, voff, rowb);  // (garbage where the :211 guard fired, rk < 0: unused)
 #pragma unroll
-            for (int e = 0; e < 21; e++) d.X[e] = hx_ld<BLK>(r, voff, (unsigned)e, rowb);
+            for (int e = 0; e < 21; e++) d.X[e] = hx_ld<BLK>(r, voff, (unsigned)e, rowb, dt1.o21);
         }
-        hx_load_vec<BLK>(a.S_MINUS, t1, lay, d.Sm1);
+        hx_load_vec<BLK>(w.S_MINUS, HexAt{dt1.o6}, lay, d.Sm1);
 #if !EPI_HEX_BWD_RECOMPUTE
-        hx_load_col<BLK>(a.P_MINUS, t1, lay, j, d.Pm1c);
+        hx_load_col<BLK>(w.P_MINUS, HexAt{dt1.o36}, lay, j, d.Pm1c);
 #endif
 #endif
     };
-    auto step = [&](int k, const HexBwdIn &cur) __attribute__((always_inline)) {
-        const int t = tpos<FLIP>(k, T);
+    auto step = [&](const HexDay &dt, const HexBwdIn &cur) __attribute__((always_inline)) {
 #if EPI_HEX_SHARE_LOADS
         double Sp[M], Sm1[M], X[24];
         hx_gather6(vSpg, j, cur.Spj, Sp);
@@ -778,36 +894,60 @@ __global__ __launch_bounds__(kWave) void eks_bwd_hex(const KArgs a, const int *_
         }
 #pragma unroll
         for (int i = 0; i < M; i++) Ss[i] = Sn[i];
-        hx_store_word(a.pinv_rank, t, lay, h, (int32_t)rank);
-        hx_store_elem<BLK>(a.S_SMOOTH, t, lay, h, hx_pick(Ss, j));
-        hx_store_col<BLK>(a.P_SMOOTH, t, lay, h, Psc);
+        hx_store_word(w.pinv_rank, HexAt{dt.o1 >> 1}, lay, h, (int32_t)rank);
+        hx_store_elem<BLK>(w.S_SMOOTH, HexAt{dt.o6}, lay, h, hx_pick(Ss, j));
+        hx_store_col<BLK>(w.P_SMOOTH, HexAt{dt.o36}, lay, h, Psc);
         if (a.u_opt_smooth) {                                               // :229 -- only the control NlinStateUpdate returns is kept
             double ur[2], tm_unused[2];
             hx_resolve(p, np, a.mf, Ss[5], cur.u, ur, tm_unused);
-            hx_store_u<BLK>(a.u_opt_smooth, a, t, lay, h, ur);
+            hx_store_u<BLK>(w.u_opt_smooth, a, HexAt{dt.on}, lay, h, ur);
         }
     };
-    if constexpr (!PF) {
-        for (int k = k_from; k >= k_to; k--) {
-            HexBwdIn cur;
-            fetch(k, cur);
-            step(k, cur);
+    // The days of the steps, walked with k: step k - 1 lies one day EARLIER in filter order (later in the array when FLIP).
+    // One addressing window per pass of the outer loop: steps k = hi ... lo; it touches the days of steps lo - 1 (the inputs of
+    // the next window's first step are requested from here) ... hi + 1, and its base is the earliest of them.
+    constexpr int DIR = FLIP ? 1 : -1;
+    const HexDayStride ds = hx_day_stride(a, lay);
+    const int W = hx_window(a, lay);
+    HexBwdIn bufA, bufB;
+    int k = k_from;
+    bool first = true;
+    if (k_from >= T - 2 && k_from < k_to) {      // T == 1: no step, the terminal condition alone
+        rebase(tpos<FLIP>(T - 1, T));
+        terminal();
+    }
+    while (k >= k_to) {
+        const int hi = k, lo = (hi - k_to >= W) ? hi - W + 1 : k_to;
+        rebase(FLIP ? tpos<FLIP>(hi + 1, T) : (lo > 0 ? lo - 1 : 0));
+        HexDay d1 = hx_day(ds, tpos<FLIP>(hi + 1, T) - tw), d0 = hx_day(ds, tpos<FLIP>(hi, T) - tw);      // days of steps k + 1, k
+        if (first && k_from >= T - 2) terminal();
+        if constexpr (!PF) {
+            for (; k >= lo; k--) {
+                fetch(d0, d1, bufA);
+                step(d0, bufA);
+                d1 = d0;
+                d0 = hx_day_next<DIR>(d0, ds);
+            }
+        } else {
+            // two input sets used alternately (the loop body exists twice): the prefetched values are consumed where they landed; a
+            // window that is not the last has an even number of steps and hands bufA to the next
+            if (first) {
+                fetch(d0, d1, bufA);
+                __builtin_amdgcn_s_waitcnt(0);       // see ekf_fwd_hex: the loop must not inherit the prologue's pending loads
+            }
+            while (k >= lo) {
+                const HexDay dm1 = hx_day_next<DIR>(d0, ds);                    // day of step k - 1 (never used when there is none)
+                if (k > k_to) fetch(dm1, d0, bufB);
+                step(d0, bufA);
+                if (--k < lo) break;
+                const HexDay dm2 = hx_day_next<DIR>(dm1, ds);
+                if (k > k_to) fetch(dm2, dm1, bufA);
+                step(dm1, bufB);
+                --k;
+                d0 = dm2;
+            }
         }
-    } else
-    // two input sets used alternately (the loop body exists twice): the prefetched values are consumed where they landed
-    {
-        HexBwdIn bufA, bufB;
-        int k = k_from;
-        if (k >= k_to) fetch(k, bufA);
-        __builtin_amdgcn_s_waitcnt(0);           // see ekf_fwd_hex: the loop must not inherit the prologue's pending loads
-        while (k >= k_to) {
-            if (k > k_to) fetch(k - 1, bufB);
-            step(k, bufA);
-            if (--k < k_to) break;
-            if (k > k_to) fetch(k - 1, bufA);
-            step(k, bufB);
-            --k;
-        }
+        first = false;
     }
     if (!h.live) return;
     if (k_to > 0) {        // hand-over to the launch that continues with step k_to - 1

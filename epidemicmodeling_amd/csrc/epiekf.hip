@@ -68,6 +68,7 @@ struct KArgs {
     int quad;   // 6-state generic models: four lanes per chain (ekf_quad.hpp) instead of one
     int wave;   // 6-state generic models: one WAVEFRONT per chain (ekf_wave.hpp)
     int hex;    // 6-state generic models: six lanes per chain, ten chains per wavefront (ekf_hex.hpp)
+    int hexw;   // hex kernels: days per addressing window (0: as many as 2 GiB hold, see HexWin; the tests set a few days)
     // epi_batch_desc.storage = 1: the caller's outputs are fp32 arrays (same layouts, 4-byte elements); each selected
     // one is the fp64 result rounded once.  The four forward quantities the smoother reads back are then always fp64
     // workspace (S_MINUS ... P_PLUS above) and their fp32 copies are extra stores.  Packed (sym) kernels only.
@@ -1060,7 +1061,9 @@ static int shape_of(const epi_batch_desc *d, int dev)
         if (d->shape == EPI_SHAPE_LANE || d->shape == EPI_SHAPE_QUAD || d->shape == EPI_SHAPE_HEX) return EPI_SHAPE_LANE;
         return (ok && d->B <= 2048) ? EPI_SHAPE_WAVE : EPI_SHAPE_LANE;
     }
-    const bool hex_ok = monitor_hoisted(d);        // the hex shape needs the monitor as its own kernel (R_v a per-day series) and a fixed Q_w
+    // the hex shape needs the monitor as its own kernel (R_v a per-day series) and a fixed Q_w -- and at least a few days of
+    // every array within the 2 GiB its addressing windows span (ekf_hex.hpp, hx_window): 288 B and 8 n_npi B per chain and day
+    const bool hex_ok = monitor_hoisted(d) && (long)d->B <= (1L << 20) && (long)d->n_npi * d->Su <= (1L << 25);
     // the wave shape also runs the monitor inline (a scalar, possibly adaptive R_v: ekf_fwd_wave<FLIP, 1>, round 5)
     const bool wave_ok = hex_ok || (mi.generic && d->r_mode == 0 && d->q_mode == 0 && d->path_hint != 2 &&
                                     (size_t)6 * d->L * sizeof(double) <= 48u * 1024u);
@@ -1743,6 +1746,11 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     ka.quad = shape_of(d, dev) == EPI_SHAPE_QUAD ? 1 : 0;
     ka.wave = shape_of(d, dev) == EPI_SHAPE_WAVE ? 1 : 0;
     ka.hex = shape_of(d, dev) == EPI_SHAPE_HEX ? 1 : 0;
+    {   // debug knob: a short addressing window for the hex kernels, so that tests cross many window boundaries
+        const char *w = getenv("EPIEKF_HEX_WINDOW");
+        ka.hexw = w ? atoi(w) : 0;
+        if (ka.hexw < 0) ka.hexw = 0;
+    }
     ka.stor = f32 ? 1 : 0;
     ka.bk_from = d->T - 2; ka.bk_to = 0;
     ka.c0 = 0; ka.cn = d->B;

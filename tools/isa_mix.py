@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction mix of a kernel's hot loop from hipcc's -S output (see tools/kernel_resources.py for the compile line).
 
-    python tools/isa_mix.py /tmp/epiekf.s 'ekf_fwd_quad<0, 16, 21, 0, 1>' [--dump]
+    python tools/isa_mix.py /tmp/epiekf.s 'ekf_fwd_quad<0, 16, 21, 0, 1>' [--dump] [--ops] [--inner]
 
 Finds the function, takes the largest backward-branch span as the loop and counts instructions by class."""
 import collections
@@ -27,8 +27,12 @@ def main():
     # the compiler marks loop headers ("Loop Header") and the blocks of a loop ("in Loop: Header=BBn_m"): the outermost
     # loop with the largest extent, from its header to the end of its last block
     best = (0, 0, 0)
+    inner = "--inner" in sys.argv          # the largest INNER loop instead (a kernel whose day loop sits inside a window loop)
     for lab, a in labels.items():
-        if "Loop Header" not in body[a] or "Parent Loop" in body[a]:
+        head = " ".join(body[a:a + 4])       # "Parent Loop ..." and "=> This Inner Loop Header" follow the label on their own lines
+        if "Loop Header" not in head.split(".LBB", 2)[1] if head.count(".LBB") > 1 else "Loop Header" not in head:
+            continue
+        if inner != ("Parent Loop" in head):
             continue
         tag = "Header=" + lab[2:]
         blocks = [k for k, l in enumerate(body) if k > a and tag in l and re.match(r"^\.LBB", l)]
