@@ -1073,11 +1073,12 @@ static int shape_of(const epi_batch_desc *d, int dev)
     // (round 5: with the hex shape there, one wavefront per chain wins only up to ~600 chains: 300 chains 1.59 against 1.81 ms per
     // call, 1 024 chains 2.15 against 1.84 -- profiles/r05/shape_latency.json; where the hex shape cannot run, up to one chain per SIMD)
     if (wave_ok && (long)d->B <= (hex_ok ? (long)simd_count(dev) * 5 / 8 : (long)simd_count(dev))) return EPI_SHAPE_WAVE;
-    // round 5: six lanes per chain, ten chains per wavefront (ekf_hex.hpp) up to 1.5 such wavefronts per SIMD (15 360 chains on
-    // MI355X; beyond one per SIMD its kernels run two waves per SIMD): 9 375 chains -- the shard of the headline sweep on one of 8
-    // GPUs -- 2.8 ms against 3.1 (quad) and 4.9 (lane), 12 500 chains 3.9-4.0 against 5.0 (lane), 18 750 level with the lane shape
-    // (5.64 against 5.70), 20 480 behind it (6.07 against 5.85): profiles/r05/hex_ab.txt
-    if (hex_ok && 2 * (((long)d->B + kHG - 1) / kHG) <= 3 * (long)simd_count(dev)) return EPI_SHAPE_HEX;
+    // round 5: six lanes per chain, ten chains per wavefront (ekf_hex.hpp) up to TWO such wavefronts per SIMD (20 480 chains on
+    // MI355X; beyond one per SIMD its kernels run two waves per SIMD, a third does not fit their registers): 9 375 chains -- the
+    // shard of the headline sweep on one of 8 GPUs -- 2.6 ms against 3.2 (quad) and 4.9 (lane); 18 750 chains (one of 4 GPUs)
+    // 5.1 against 5.6 (lane), 20 480 chains 5.5 against 5.7, 20 500 chains 6.5 against 5.8: profiles/r05/ab_hex_threshold.txt
+    // (with the kernels' day offsets in the scalar offset; before that the shapes were level at 18 750)
+    if (hex_ok && ((long)d->B + kHG - 1) / kHG <= 2 * (long)simd_count(dev)) return EPI_SHAPE_HEX;
     return ((long)d->B + kQC - 1) / kQC <= (long)simd_count(dev) ? EPI_SHAPE_QUAD : EPI_SHAPE_LANE;
 }
 

@@ -156,8 +156,8 @@ typedef struct epi_batch_desc {
                              covariances are symmetric bit for bit, so every product needs one transpose through LDS and the
                              Jacobian's zeros are skipped -- about half the quad shape's instructions per day; same conditions
                              as 3, except that a scalar R_v falls back to 2).  Auto: 3 up to 640 chains (up to 1 024 with a
-                             scalar R_v, whose monitor the wave shape runs inline), 4 up to 15 360 (the 9 375-chain shard of the
-                             headline sweep on one of 8 GPUs: 2.8 ms against 3.1 with 2 and 4.9 with 1), 2 up to 16 384 where 4
+                             scalar R_v, whose monitor the wave shape runs inline), 4 up to 20 480 (the 9 375-chain shard of the
+                             headline sweep on one of 8 GPUs: 2.6 ms against 3.2 with 2 and 4.9 with 1), 2 up to 16 384 where 4
                              cannot run, then 1.
                              The 3-state generic models know 1 and 3 (there: SEVEN chains per wavefront, nine lanes each,
                              ekf_fwd_wave3 / eks_bwd_wave3; auto: 3 up to 2 048 chains).  Results are bit-identical in all
