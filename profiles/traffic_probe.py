@@ -36,6 +36,8 @@ if "wave250" in args:             # a region's 250 cost weights: the one-wavefro
     w = synth.make_cfg4(1, 250)
 elif "cfg5" in args:              # BASELINE config 5: 307 200 3-state chains x 400 days, fp32 storage
     w = synth.make_cfg5(300, 1024, 400)
+elif "shard4" in args:            # the 18 750-chain shard one of 4 GPUs runs: the hex kernels at two waves per SIMD
+    w = synth.make_cfg4(150, 125)
 else:
     w = synth.make_cfg4(75, 125, live="live" in args) if "shard" in args else synth.make_cfg4(live="live" in args)
 outs = ["u_opt_smooth", "S_SMOOTH"] if "reduced" in args else None
