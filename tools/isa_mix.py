@@ -17,7 +17,7 @@ def main():
     # function starts: "<mangled>:" following a .type ...,@function
     starts = [(i, m.group(1)) for i, l in enumerate(lines) if (m := re.match(r"^(_Z\w+):", l))]
     names = subprocess.run(["c++filt"] + [s[1] for s in starts], capture_output=True, text=True, stdin=subprocess.DEVNULL, timeout=60).stdout.split("\n")
-    sel = [(s, n) for s, n in zip(starts, names) if want in n]
+    sel = [(s, n) for s, n in zip(starts, names) if want in n.replace("epi::", "")]
     if not sel:
         sys.exit("no kernel matches " + want)
     (i0, mangled), name = sel[0]
