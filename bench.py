@@ -73,6 +73,11 @@ def parse():
                     help="one-time set-up before the first pass (EkfRunner.tune_placement): time a staged pass on this many "
                          "allocations of the outputs + workspace and keep the fastest (where the allocator puts the ~14 concurrently "
                          "streamed arrays changes a pass by up to 15 %, DESIGN.md 5); 1 = take what the allocator gives")
+    ap.add_argument("--spinup-ms", type=float, default=200.0,
+                    help="set-up, before the W warm-up passes: keep running passes until this much wall time has gone by, so that the "
+                         "device is at its steady clocks when the timed region starts -- after an idle second the first ~50-150 ms of "
+                         "work run 3-15 %% slower (profiles/r05/clock_ramp.txt), which a 2.5 ms pass would carry into ten timed passes "
+                         "and a 15.6 ms pass would not; 0 = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chains", type=int, default=0, help="0 = sized for ~15 s")
     return ap.parse_args()
@@ -359,6 +364,23 @@ def main():
     # EPI_BENCH_STAGED=1: every pass -- warm-up included -- is enqueued stage by stage, so that a `rocprofv3 --stats` of the run
     # sees ONE kind of launch per kernel and its averages are the per-kernel durations `roofline` quotes
     staged = os.environ.get("EPI_BENCH_STAGED") == "1"
+    spin_passes = 0
+    if args.spinup_ms > 0:        # set-up: the device at its steady clocks before the warm-up passes (see --spinup-ms)
+        def spin_step():
+            one_step([torch.cuda.Event(enable_timing=True) for _ in range(4)] if staged else None)
+        t_spin = time.perf_counter()
+        spin_step()
+        torch.cuda.synchronize(dev)
+        est_ms = max((time.perf_counter() - t_spin) * 1e3, 1e-3)
+        spin_passes = max(int(np.ceil(args.spinup_ms / est_ms)) - 1, 0)
+        if world > 1:             # the passes contain the gather: every rank must run the same number of them
+            tn = torch.tensor([spin_passes], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            spin_passes = int(tn.item())
+        for _ in range(spin_passes):
+            spin_step()
+        torch.cuda.synchronize(dev)
+        spin_passes += 1
     for _ in range(args.warmup):
         one_step([torch.cuda.Event(enable_timing=True) for _ in range(4)] if staged else None)
     torch.cuda.synchronize(dev)
@@ -434,7 +456,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (strong or world == 1) and args.scaling == "strong" else "weak",
             "vs_baseline": None, "dtype": "f64" if args.storage == "f64" else "f64 arithmetic, f32 storage", "data": "synthetic",
-            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "time_pipe": args.time_pipe,
+            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "time_pipe": args.time_pipe, "spinup_ms": args.spinup_ms, "spinup_passes": spin_passes,
                        "lane_block": runner.blk, "shape": ("wave (one wavefront per chain)" if m == 6 else "wave (seven 9-lane chains per wavefront)") if runner.blk == 1 and w.B > 1 else (("quad (4 lanes per chain)" if runner.blk == 16 else ("hex (6 lanes per chain)" if runner.blk == 10 else "lane (1 lane per chain)")) if m == 6 else "lane (1 lane per chain)"),
                        "sweep_chains_total": B_total,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
