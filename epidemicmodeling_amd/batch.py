@@ -157,26 +157,41 @@ class EkfRunner:
         self.outs.pinv_rank = _ptr(self.pinv_rank)
         self.outs.status = _ptr(self.status)
 
-    def stage_ms(self, passes=2):
+    def stage_ms(self, passes=2, min_ms=0.0):
         """(forward, pinv, smoother) milliseconds of a pass enqueued stage by stage (HIP events on the current stream), the
-        mean over `passes` after one untimed pass."""
+        mean over `passes` after one untimed pass -- over as many more as it takes to fill `min_ms` of work, so that short
+        passes are not compared on two samples."""
+        import time
         dev = self.dw.device
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
         self.run(phase=1); self.run(phase=3); self.run(phase=4)
+        torch.cuda.synchronize(dev)
+        one = max((time.perf_counter() - t0) * 1e3, 1e-3)
+        passes = max(int(passes), int(np.ceil(min_ms / one)))
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(passes)]
         for e in ev:
             e[0].record(); self.run(phase=1); e[1].record(); self.run(phase=3); e[2].record(); self.run(phase=4); e[3].record()
         torch.cuda.synchronize(dev)
         return tuple(float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i in range(3))
 
-    def tune_placement(self, tries=3):
+    def tune_placement(self, tries=3, spinup_ms=150.0):
         """Where the allocator puts the ~14 arrays a pass streams concurrently changes the forward kernel's and the smoother's
         time by up to 15 % (they meet in the physically indexed L2's sets and banks or they do not: DESIGN.md 5, "where the
         arrays lie"), it is a property of the ALLOCATION -- the same arrays give the same time run after run -- and the caller
         cannot see it.  So: time a staged pass on this allocation, allocate the outputs and the workspace again (`tries` - 1
         times, each while the earlier ones are still held, so that other memory is handed out), keep the fastest and free the
         rest.  One-time set-up cost: a few passes and, transiently, `tries` x the outputs' memory (skipped when that does not
-        fit).  Returns {"tries": [...ms per try...], "chosen": i}."""
+        fit).  The device is brought to its steady clocks first (`spinup_ms` of passes: after idle the first 50-150 ms of work
+        run up to 15 % slower, which would make the FIRST try look bad whatever its placement) and every try is timed over at
+        least 15 ms of work.  Returns {"tries": [...ms per try...], "chosen": i}."""
+        import time
         dev = self.dw.device
+        if int(tries) > 1 and spinup_ms > 0:
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < spinup_ms:
+                self.run()
+                torch.cuda.synchronize(dev)
         held, log = [], []
         need = sum(t.numel() * t.element_size() for t in self.out.values()) + self.ws.numel() * 8
         for i in range(max(1, int(tries))):
@@ -186,7 +201,7 @@ class EkfRunner:
                     break
                 self._allocate()
                 self._bind()
-            f, p, b = self.stage_ms()
+            f, p, b = self.stage_ms(min_ms=15.0)
             log.append({"fwd_ms": f, "pinv_ms": p, "bwd_ms": b, "sum_ms": f + p + b})
             held.append((self.out, self.ws, self._slab))
         best = int(np.argmin([x["sum_ms"] for x in log]))
