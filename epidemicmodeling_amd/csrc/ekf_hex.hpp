@@ -229,9 +229,9 @@ EPI_DEV HexDayStride hx_day_stride(const KArgs &a, const Lay &l)
 // the widest array short of the record count (the prefetch reaches one day beyond the window on either side)
 EPI_DEV int hx_window(const KArgs &a, const Lay &l)
 {
-    if (a.hexw >= 2) return a.hexw & ~1;
     const unsigned s36 = l.bp * 288u, su = (unsigned)a.n_npi * (unsigned)a.Su * 8u;
-    const int w = (int)(kHexRecords / (s36 > su ? s36 : su)) - 3;
+    int w = (int)(kHexRecords / (s36 > su ? s36 : su)) - 3;
+    if (a.hexw >= 2 && a.hexw < w) w = a.hexw;         // the test knob can only shorten the window
     return w < 2 ? 2 : (w & ~1);
 }
 template <class P> EPI_DEV P *hx_rebase(P *p, int tw, size_t elems_per_day) { return p ? p + (size_t)tw * elems_per_day : nullptr; }
