@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "epiekf.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "csrc", "ekf_sym.hpp"), os.path.join(HERE, "csrc", "ekf_quad.hpp"), os.path.join(HERE, "csrc", "ekf_wave.hpp"), os.path.join(HERE, "csrc", "ekf_hex.hpp"),
+DEPS = [SRC, os.path.join(HERE, "csrc", "ekf_device.hpp"), os.path.join(HERE, "csrc", "ekf_sym.hpp"), os.path.join(HERE, "csrc", "ekf_quad.hpp"), os.path.join(HERE, "csrc", "ekf_wave.hpp"), os.path.join(HERE, "csrc", "ekf_hex.hpp"), os.path.join(HERE, "csrc", "ekf_lane6.hpp"),
         os.path.join(HERE, "csrc", "scenario_kernels.hpp"), os.path.join(HERE, "csrc", "rt_expfit.hpp"), os.path.join(HERE, "csrc", "preprocess.hpp"), os.path.join(HERE, "csrc", "nnls.hpp"),
         os.path.join(HERE, "..", "include", "epiekf.h"), os.path.join(HERE, "..", "include", "epiekf_layout.h")]
 LIB = os.path.join(HERE, "libepiekf.so")

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # EPIEKF_LIB: load another build of the same ABI instead (A/B measurements of kernel variants)
 LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 
-ABI_VERSION = 5      # EPIEKF_ABI_VERSION of include/epiekf.h
+ABI_VERSION = 6      # EPIEKF_ABI_VERSION of include/epiekf.h
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
     "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_ekf_run_host_multi", "epi_host_pool_release", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
@@ -38,7 +38,8 @@ class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "model", "B", "T", "Sx", "Su", "n_npi", "L", "order",
                                           "obs_type", "r_mode", "q_mode")] + [
         ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("time_pipe", C.c_int32),
-        ("lane_block", C.c_int32), ("shape", C.c_int32), ("storage", C.c_int32), ("exact_nonfinite", C.c_int32)]
+        ("lane_block", C.c_int32), ("shape", C.c_int32), ("storage", C.c_int32), ("exact_nonfinite", C.c_int32),
+        ("test_window", C.c_int32), ("test_flags", C.c_int32)]       # test hooks, 0 in production (include/epiekf.h)
 
 
 class Inputs(C.Structure):
@@ -238,4 +239,5 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask,
         d.obs_type = int(obs_type)
     d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), int(q_mode), int(out_mask), 0
     d.path_hint, d.time_pipe, d.lane_block, d.shape, d.storage, d.exact_nonfinite = 0, 0, 0, 0, 0, 0
+    d.test_window, d.test_flags = 0, 0
     return d

@@ -62,7 +62,7 @@ class EkfRunner:
     """Pre-allocated outputs + workspace for a DeviceWorkload; run() only enqueues kernels."""
 
     def __init__(self, dw: DeviceWorkload, outputs=None, extras=False, time_pipe=0, precheck=True, lane_block=0, shape=0,
-                 storage="f64", exact_nonfinite=None, slab=None):
+                 storage="f64", exact_nonfinite=None, slab=None, test_window=0, test_flags=0):
         """time_pipe: epi_batch_desc.time_pipe (0 = the library decides whether a full call runs its forward kernel in time
         segments with the pinv grid of each segment beside the next, 1 = on, -1 = off).  precheck: ask the
         library once (synchronously) whether the batch qualifies for the symmetric-packed kernels, so that
@@ -85,6 +85,8 @@ class EkfRunner:
         # (their Inf / NaN pattern is then the dense evaluation's, i.e. the reference's)
         # None = the library's default (on whenever the smoother runs), True = always, False = off
         self.desc.exact_nonfinite = 0 if exact_nonfinite is None else (1 if exact_nonfinite else -1)
+        # test hooks (epi_batch_desc.test_window / test_flags, 0 in production): short addressing windows, forced reverse-time pipeline
+        self.desc.test_window, self.desc.test_flags = int(test_window), int(test_flags)
         odt = torch.float32 if storage == "f32" else torch.float64
         if lane_block == "auto":       # one block per wavefront of the launch
             lane_block = int(_lib.lib().epi_ekf_preferred_lane_block(C.byref(self.desc)))
@@ -278,11 +280,11 @@ class EkfRunner:
 
 
 def run_workload(w, outputs=None, device="cuda:0", extras=True, time_pipe=0, precheck=True, lane_block=0, shape=0, storage="f64",
-                 exact_nonfinite=None):
+                 exact_nonfinite=None, test_window=0, test_flags=0):
     """Convenience: upload `w`, run once, return dict name -> numpy array [T, rows, B] (+ pinv_rank/status)."""
     dw = DeviceWorkload(w, device)
     r = EkfRunner(dw, outputs, extras=extras, time_pipe=time_pipe, precheck=precheck, lane_block=lane_block, shape=shape, storage=storage,
-                  exact_nonfinite=exact_nonfinite)
+                  exact_nonfinite=exact_nonfinite, test_window=test_window, test_flags=test_flags)
     r.run()
     torch.cuda.synchronize(dw.device)
     res = {n: r.unblocked(n).cpu().numpy() for n in r.out}

@@ -731,6 +731,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd(const KArgs a)
 #include "ekf_quad.hpp"
 #include "ekf_wave.hpp"
 #include "ekf_hex.hpp"
+#include "ekf_lane6.hpp"
 
 // ---------------------------------------------------------------------------
 // forward simulators
@@ -1149,6 +1150,7 @@ struct Tail {
 // what one call enqueues
 struct Launch {
     int dev, phase, hint, time_pipe;
+    int test_flags;  // epi_batch_desc.test_flags (0 in production)
     bool smooth;
     const Tail *tail;
     bool rerun;      // epi_batch_desc.exact_nonfinite: dense second pass over the chains whose covariance went non-finite
@@ -1372,6 +1374,21 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
                 done = true;
             }
         }
+        if constexpr (M == 6 && GENERIC) {
+            // one lane per chain with fixed descriptors per addressing window (ekf_lane6.hpp): the layout block must be the
+            // lanes a workgroup uses, and a compile-time constant
+            if (!done && EPI_LANE6_BWD && !ka.stor && lane6_block(ka.blk) && (long)ka.blk * ka.nblk <= (1L << 20)) {
+                const int lblocks = (ka.B + ka.blk - 1) / ka.blk;
+#if EPI_LANE6_BWD == 3
+                if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6d<FLIP, 40>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+#else
+                if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 40, (EPI_LANE6_BWD > 1)>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+#endif
+                else if (ka.blk == 48) hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 48, (EPI_LANE6_BWD > 1)>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 56, (EPI_LANE6_BWD > 1)>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                done = true;
+            }
+        }
         if (!done) {
             if (ka.stor) hipLaunchKernelGGL((eks_bwd_sym<M, FLIP, 1>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
             else hipLaunchKernelGGL((eks_bwd_sym<M, FLIP>), dim3(blocks), dim3(kWave), 0, st, ka, ka.dense_flag);
@@ -1520,7 +1537,8 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
     };
     const long fwd_waves = ka.hex ? ((long)ka.B + kHG - 1) / kHG : ka.quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
     // (one wavefront per chain: the pinv grid of so few chains takes ~30 us, nothing to pipeline -- unless asked for)
-    const bool tp = ka.mon_hoist && !ka.stor && T >= 128 && L.time_pipe >= 0 &&
+    const bool force_rp = (L.test_flags & 1) && ka.hex && ka.mon_hoist && T >= 4 && L.time_pipe >= 0;      // test hook
+    const bool tp = !force_rp && ka.mon_hoist && !ka.stor && T >= 128 && L.time_pipe >= 0 &&
                     (L.time_pipe == 1 || (!ka.wave && fwd_waves * 4 <= (long)simd_count(L.dev) * 3));
     bool helper_busy = false;
     // Pipelined in REVERSE time (round 5, the hex shape): the smoother consumes X = pinv(P(k+1|k)) from the last day backwards, so
@@ -1531,7 +1549,7 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
 #ifndef EPI_REVERSE_PIPE
 #define EPI_REVERSE_PIPE 1
 #endif
-    const bool rp = EPI_REVERSE_PIPE && !tp && ka.hex && ka.mon_hoist && T >= 128 && L.time_pipe >= 0;
+    const bool rp = force_rp || (EPI_REVERSE_PIPE && !tp && ka.hex && ka.mon_hoist && T >= 128 && L.time_pipe >= 0);
     if (rp) {
         if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         if ((e = fork(st, h->stream)) != hipSuccess) return e;
@@ -1554,7 +1572,7 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
             seg_hi[ns] = top; seg_lo[ns] = L.tail->t_hist; tail_seg = ns; ns++;
             top = L.tail->t_hist - 1;
         }
-        const int parts = (top + 1 >= 96) ? EPI_RP_PARTS : 1;
+        const int parts = (top + 1 >= 96 || (force_rp && top + 1 >= 6)) ? EPI_RP_PARTS : 1;
         for (int q = 0; q < parts; q++) {
             const int lo = (int)((long)(top + 1) * (parts - 1 - q) / parts);
             seg_hi[ns] = top; seg_lo[ns] = lo; ns++;
@@ -1686,6 +1704,8 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->shape < 0 || d->shape > 4) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain), 2 (four lanes per chain), 3 (one wavefront per chain) or 4 (six lanes per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
     if (d->exact_nonfinite < -1 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 (default: on), 1 (on) or -1 (off)"); return EPI_ERR_BAD_ARG; }
+    if (d->test_window < 0 || d->test_window == 1) { set_err(err, "test_window must be 0 (production) or >= 2"); return EPI_ERR_BAD_ARG; }
+    if (d->test_flags < 0 || d->test_flags > 1) { set_err(err, "test_flags must be 0 (production) or 1"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
@@ -1747,11 +1767,7 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     ka.quad = shape_of(d, dev) == EPI_SHAPE_QUAD ? 1 : 0;
     ka.wave = shape_of(d, dev) == EPI_SHAPE_WAVE ? 1 : 0;
     ka.hex = shape_of(d, dev) == EPI_SHAPE_HEX ? 1 : 0;
-    {   // debug knob: a short addressing window for the hex kernels, so that tests cross many window boundaries
-        const char *w = getenv("EPIEKF_HEX_WINDOW");
-        ka.hexw = w ? atoi(w) : 0;
-        if (ka.hexw < 0) ka.hexw = 0;
-    }
+    ka.hexw = d->test_window;      // test hook (0 in production): days per addressing window, see epi_batch_desc.test_window
     ka.stor = f32 ? 1 : 0;
     ka.bk_from = d->T - 2; ka.bk_to = 0;
     ka.c0 = 0; ka.cn = d->B;
@@ -1823,7 +1839,7 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     const bool smooth = smooth_sel || rerun;
     hipStream_t st = (hipStream_t)stream;
     Launch L{};
-    L.dev = dev; L.phase = d->phase; L.time_pipe = d->time_pipe; L.smooth = smooth; L.tail = tail; L.rerun = rerun;
+    L.dev = dev; L.phase = d->phase; L.time_pipe = d->time_pipe; L.test_flags = d->test_flags; L.smooth = smooth; L.tail = tail; L.rerun = rerun;
     // a time-varying Q_w is read per step by the dense kernels only
     L.hint = (mi.generic && d->q_mode == 0) ? d->path_hint : 2;
     if (tail && (!ka.u_opt_smooth || d->phase != 0)) { set_err(err, "the sweep's scoring tail needs a full call (phase 0) with fp64 u_opt_smooth selected"); return EPI_ERR_BAD_ARG; }

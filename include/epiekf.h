@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define EPIEKF_ABI_VERSION 5
+#define EPIEKF_ABI_VERSION 6
 
 /* which reference function the chain runs */
 typedef enum epi_model {
@@ -180,6 +180,15 @@ typedef struct epi_batch_desc {
                              walks the list of marked chains); (2 B + 1 + B) more int32 of workspace.  The *_host entry points
                              reach the same result without device-side launches: epi_ekf_run_host[_multi] look at the status
                              words that come back with the outputs and enqueue the second pass only when a chain is marked. */
+    /* TEST HOOKS (ABI 6; until ABI 5 an environment variable read on every call).  Both are 0 in production: a default-
+       constructed descriptor never sets them, nothing else in the library reads process-global state.  They only choose
+       code paths that the batch size otherwise chooses, so that small tests reach them; results are identical for every value. */
+    int32_t test_window;  /* > 0: the kernels that keep their buffer descriptors fixed over an addressing window of days (the hex
+                             shape, ekf_hex.hpp; the one-lane kernels of ekf_lane6.hpp) use windows of at most that many days
+                             (>= 2) instead of as many as fit 2 GiB.  It can only SHORTEN the window. */
+    int32_t test_flags;   /* bit 0: a full call in the hex shape takes the reverse-time pipeline (pinv grids of the earlier days
+                             beside the smoother's first launches) whatever the batch size and day count, which otherwise
+                             engages beyond 768 hex wavefronts and 128 days only. */
 } epi_batch_desc;
 
 typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3, EPI_SHAPE_HEX = 4 } epi_shape;

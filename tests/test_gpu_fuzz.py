@@ -77,11 +77,14 @@ def build(draw):
     # process noise: diagonal (packed kernels) or full (dense fallback)
     if generic and draw(st.sampled_from([False, False, True])):
         w.Q = w.Q.copy(); w.Q[1] = 1e-13
-    lane_block = draw(st.sampled_from([0, 0, 3, 8, 16, 32, "auto"]))
+    lane_block = draw(st.sampled_from([0, 0, 3, 8, 16, 32, 40, "auto"]))
     time_pipe = draw(st.sampled_from([0, 0, 1, -1]))
     # lane mapping of the 6-state generic models: one lane per chain, four lanes per chain, or the library's own choice
     shape = draw(st.sampled_from(["lane", "quad", "wave", "hex", "hex", "auto"]))
-    return w, lane_block, time_pipe, kind, shape
+    # test hooks of the descriptor: short addressing windows (hex and fixed-descriptor lane kernels), the reverse-time pipeline
+    # at a batch size that would not choose it
+    hooks = dict(test_window=draw(st.sampled_from([0, 0, 2, 3, 6])), test_flags=draw(st.sampled_from([0, 0, 1])))
+    return w, lane_block, time_pipe, kind, shape, hooks
 
 
 # EPI_FUZZ_EXAMPLES=n runs n freshly drawn examples instead of the fixed 200 (a longer hunt; default stays reproducible)
@@ -92,13 +95,13 @@ _N = int(os.environ.get("EPI_FUZZ_EXAMPLES", "0"))
 @given(st.data())
 def test_random_problems_match_the_oracle(gpu_device, data):
     from epidemicmodeling_amd import batch
-    w, lane_block, time_pipe, kind, shape = build(data.draw)
+    w, lane_block, time_pipe, kind, shape, hooks = build(data.draw)
     ref = H.oracle_batch(w)
-    got = batch.run_workload(w, device=gpu_device, lane_block=lane_block, time_pipe=time_pipe, shape=shape, exact_nonfinite=True)
+    got = batch.run_workload(w, device=gpu_device, lane_block=lane_block, time_pipe=time_pipe, shape=shape, exact_nonfinite=True, **hooks)
     for n in H.OUT_NAMES:
         if n in ref and n in got:
-            assert np.array_equal(got[n], ref[n], equal_nan=True), (kind, w.T, w.B, w.L, lane_block, time_pipe, shape, n)
-    assert np.array_equal(got["pinv_rank"], ref["pinv_rank"]), (kind, w.T, w.B, shape)
+            assert np.array_equal(got[n], ref[n], equal_nan=True), (kind, w.T, w.B, w.L, lane_block, time_pipe, shape, hooks, n)
+    assert np.array_equal(got["pinv_rank"], ref["pinv_rank"]), (kind, w.T, w.B, shape, hooks)
     if not w.model.startswith("NewCase"):
         assert np.array_equal((got["status"] & 1).astype(bool), H.oracle_guard_fired(ref, w.model)), (kind, w.T, w.B, shape)
 
@@ -126,6 +129,7 @@ def test_random_sweeps_through_the_one_call_entry(gpu_device, data):
     lane_block = draw(st.sampled_from([0, 0, 8, 16, 40, "auto"]))
     shape = draw(st.sampled_from(["lane", "quad", "wave", "hex", "auto"]))
     time_pipe = draw(st.sampled_from([0, 1, -1]))
+    hooks = dict(test_window=draw(st.sampled_from([0, 0, 2, 5])), test_flags=draw(st.sampled_from([0, 1])))
     with_front = draw(st.booleans())
     n, B = w.n_npi, w.B
     sp = np.zeros((batch.SIM_PRM_COUNT, B))
@@ -139,12 +143,12 @@ def test_random_sweeps_through_the_one_call_entry(gpu_device, data):
     sp_d, j0_d, j1_d = to(sp), to(rng.random(B) * 1e-2), to(rng.random(B) * 40.0)
     ref = H.oracle_batch(w)
     dw = batch.DeviceWorkload(w, gpu_device)
-    r = batch.EkfRunner(dw, outputs=outputs, extras=True, lane_block=lane_block, shape=shape, time_pipe=time_pipe)
+    r = batch.EkfRunner(dw, outputs=outputs, extras=True, lane_block=lane_block, shape=shape, time_pipe=time_pipe, **hooks)
     for t in list(r.out.values()) + [r.ws]:
         t.fill_(float("nan"))
     sc = r.run_sweep(T_hist, sp_d, j0_d, j1_d, n_regions=R if with_front else None)
     torch.cuda.synchronize()
-    tag = (R, E, T_hist, hor, outputs, lane_block, shape, time_pipe, with_front)
+    tag = (R, E, T_hist, hor, outputs, lane_block, shape, time_pipe, hooks, with_front)
     for nme in r.out:
         assert np.array_equal(r.unblocked(nme).cpu().numpy(), ref[nme], equal_nan=True), (tag, nme)
     assert np.array_equal(r.unblocked("pinv_rank").cpu().numpy(), ref["pinv_rank"]), tag

@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6: parity of one build of the library on the lane6 tests + the full-size headline test, then A/B of builds
+# usage: tools/r6_ab2.sh "parity_lib.so ..." "ab libs" REPS [bench args]
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+for L in $1; do
+  EPIEKF_LIB=$GRAFT_REPO_ROOT/ab/$L timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "lane6 or headline_sweep_at_full_size" > gpurun_out/r06/parity_$L.txt 2>&1 || { tail -40 gpurun_out/r06/parity_$L.txt; exit 1; }
+  tail -2 gpurun_out/r06/parity_$L.txt
+done
+LIBS=$2; REPS=$3; shift 3
+bash tools/ab_variants.sh "$LIBS" $REPS "$@"
