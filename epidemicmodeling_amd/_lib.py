@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("EPIEKF_LIB") or os.path.join(HERE, "libepiekf.so")
 ABI_VERSION = 6      # EPIEKF_ABI_VERSION of include/epiekf.h
 ABI_SYMBOLS = [
     "epi_abi_version", "epi_status_string", "epi_model_dim", "epi_ekf_validate", "epi_ekf_workspace_bytes",
-    "epi_ekf_precheck_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_ekf_run_host_multi", "epi_host_pool_release", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
+    "epi_ekf_precheck_device", "epi_ekf_time_stages_device", "epi_ekf_preferred_lane_block", "epi_ekf_run_device", "epi_ekf_run_host", "epi_ekf_run_host_multi", "epi_host_pool_release", "epi_sialpha_sim_device", "epi_sialpha_score_device", "epi_seirp_sim_device",
     "epi_random_npi_mc_device", "epi_pareto_front_device", "epi_npi_cost_device", "epi_si_controlled_device", "epi_si_controlled_host", "epi_sialpha_sim_host", "epi_seirp_sim_host", "epi_npi_cost_host", "epi_calib_copy_f64_device",
     "epi_rt_expfit_validate", "epi_rt_expfit_run_device", "epi_rt_expfit_run_host",
     "epi_preprocess_workspace_bytes", "epi_preprocess_device", "epi_nnls_affine_fit_device",
@@ -39,7 +39,8 @@ class BatchDesc(C.Structure):
                                           "obs_type", "r_mode", "q_mode")] + [
         ("out_mask", C.c_uint32), ("phase", C.c_int32), ("path_hint", C.c_int32), ("time_pipe", C.c_int32),
         ("lane_block", C.c_int32), ("shape", C.c_int32), ("storage", C.c_int32), ("exact_nonfinite", C.c_int32),
-        ("test_window", C.c_int32), ("test_flags", C.c_int32)]       # test hooks, 0 in production (include/epiekf.h)
+        ("placement_tries", C.c_int32),                                  # host-pointer entry points: candidate arenas (include/epiekf.h)
+        ("test_window", C.c_int32), ("test_flags", C.c_int32)]           # test hooks, 0 in production
 
 
 class Inputs(C.Structure):
@@ -50,7 +51,11 @@ class Inputs(C.Structure):
 class Outputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("u_opt", "u_opt_smooth", "S_MINUS", "S_PLUS", "S_SMOOTH", "P_MINUS",
                                            "P_PLUS", "P_SMOOTH", "K_GAIN", "innovations", "rho", "pinv_rank",
-                                           "status")]
+                                           "status", "placement")]
+
+
+class PlacementReport(C.Structure):
+    _fields_ = [("tries", C.c_int32), ("chosen", C.c_int32), ("ms", C.c_float * 8)]
 
 
 class SweepDesc(C.Structure):
@@ -59,7 +64,7 @@ class SweepDesc(C.Structure):
 
 class PrescribeDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("abi_version", "R", "P", "T", "t_hist", "n_npi", "L", "order", "obs_type")] + [
-        ("out_mask", C.c_uint32), ("shape", C.c_int32), ("time_pipe", C.c_int32)]
+        ("out_mask", C.c_uint32), ("shape", C.c_int32), ("time_pipe", C.c_int32), ("placement_tries", C.c_int32)]
 
 
 class PrescribeInputs(C.Structure):
@@ -68,7 +73,7 @@ class PrescribeInputs(C.Structure):
 
 
 class PrescribeOutputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("J0", "J1", "on_front", "i_opt", "u_opt", "S_opt")] + [("extras", Outputs)]
+    _fields_ = [(n, C.c_void_p) for n in ("J0", "J1", "on_front", "i_opt", "u_opt", "S_opt")] + [("extras", Outputs), ("placement", C.c_void_p)]
 
 
 class SimDesc(C.Structure):
@@ -152,6 +157,9 @@ def lib():
         h.epi_ekf_run_device.restype = C.c_int
         h.epi_ekf_run_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p,
                                          C.c_size_t, C.c_void_p, C.c_char_p]
+        h.epi_ekf_time_stages_device.restype = C.c_int
+        h.epi_ekf_time_stages_device.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_void_p,
+                                                 C.c_size_t, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.c_char_p]
         h.epi_ekf_run_host.restype = C.c_int
         h.epi_ekf_run_host.argtypes = [C.POINTER(BatchDesc), C.POINTER(Inputs), C.POINTER(Outputs), C.c_int,
                                        C.c_char_p]
@@ -239,5 +247,5 @@ def make_desc(model, B, T, Sx, Su, n_npi, L_, order, obs_type, r_mode, out_mask,
         d.obs_type = int(obs_type)
     d.r_mode, d.q_mode, d.out_mask, d.phase = int(r_mode), int(q_mode), int(out_mask), 0
     d.path_hint, d.time_pipe, d.lane_block, d.shape, d.storage, d.exact_nonfinite = 0, 0, 0, 0, 0, 0
-    d.test_window, d.test_flags = 0, 0
+    d.placement_tries, d.test_window, d.test_flags = 0, 0, 0
     return d

@@ -159,23 +159,23 @@ class EkfRunner:
         self.outs.pinv_rank = _ptr(self.pinv_rank)
         self.outs.status = _ptr(self.status)
 
-    def stage_ms(self, passes=2, min_ms=0.0):
-        """(forward, pinv, smoother) milliseconds of a pass enqueued stage by stage (HIP events on the current stream), the
-        mean over `passes` after one untimed pass -- over as many more as it takes to fill `min_ms` of work, so that short
-        passes are not compared on two samples."""
-        import time
-        dev = self.dw.device
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        self.run(phase=1); self.run(phase=3); self.run(phase=4)
-        torch.cuda.synchronize(dev)
-        one = max((time.perf_counter() - t0) * 1e3, 1e-3)
-        passes = max(int(passes), int(np.ceil(min_ms / one)))
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(passes)]
-        for e in ev:
-            e[0].record(); self.run(phase=1); e[1].record(); self.run(phase=3); e[2].record(); self.run(phase=4); e[3].record()
-        torch.cuda.synchronize(dev)
-        return tuple(float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i in range(3))
+    def stage_ms(self, passes=2, min_ms=0.0, stream=None):
+        """(forward, pinv, smoother) milliseconds of a pass enqueued stage by stage -- epi_ekf_time_stages_device: HIP events on
+        the stream, one untimed round, then the mean over as many rounds as fill `min_ms` of device time (at least `passes`)."""
+        st = torch.cuda.current_stream(self.dw.device) if stream is None else stream
+        ms = (C.c_double * 3)()
+        best = None
+        # the library times until min_ms is filled; `passes` rounds at least: ask again while fewer were averaged
+        need = float(min_ms)
+        for _ in range(max(1, int(passes))):
+            rc = _lib.lib().epi_ekf_time_stages_device(C.byref(self.desc), C.byref(self.ins), C.byref(self.outs), _ptr(self.ws),
+                                                       self.ws_bytes, C.c_void_p(st.cuda_stream), need, ms, self.err)
+            _lib.check(rc, self.err)
+            cur = (float(ms[0]), float(ms[1]), float(ms[2]))
+            best = cur if best is None else tuple((a + b) for a, b in zip(best, cur))
+            if need > 0:
+                return cur
+        return tuple(x / max(1, int(passes)) for x in best)
 
     def tune_placement(self, tries=3, spinup_ms=150.0):
         """Where the allocator puts the ~14 arrays a pass streams concurrently changes the forward kernel's and the smoother's

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -1704,6 +1705,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->shape < 0 || d->shape > 4) { set_err(err, "shape must be 0 (auto), 1 (one lane per chain), 2 (four lanes per chain), 3 (one wavefront per chain) or 4 (six lanes per chain)"); return EPI_ERR_BAD_ARG; }
     if (d->storage < 0 || d->storage > 1) { set_err(err, "storage must be 0 (fp64) or 1 (fp32)"); return EPI_ERR_BAD_ARG; }
     if (d->exact_nonfinite < -1 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 (default: on), 1 (on) or -1 (off)"); return EPI_ERR_BAD_ARG; }
+    if (d->placement_tries < 0 || d->placement_tries > EPI_PLACEMENT_MAX_TRIES) { set_err(err, "placement_tries must be 0 .. EPI_PLACEMENT_MAX_TRIES"); return EPI_ERR_BAD_ARG; }
     if (d->test_window < 0 || d->test_window == 1) { set_err(err, "test_window must be 0 (production) or >= 2"); return EPI_ERR_BAD_ARG; }
     if (d->test_flags < 0 || d->test_flags > 1) { set_err(err, "test_flags must be 0 (production) or 1"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
@@ -1895,6 +1897,45 @@ int epi_sweep_run_device(const epi_batch_desc *d, const epi_inputs *in, const ep
     return run_device_impl(&full, in, out, workspace, workspace_bytes, &t, stream, err);
 }
 
+// (forward + monitor, pinv grid, smoother) milliseconds of this call on THESE arrays, enqueued stage by stage (phases 1, 3, 4)
+// between HIP events on `stream`: the mean over as many rounds as fill `min_ms` of device time (at least one), after one untimed
+// round.  Synchronous.  What a device-pointer caller compares allocations with ("Placement"): the same arrays give the
+// same times run after run, another allocation of the same arrays may be 5-15 % off.
+int epi_ekf_time_stages_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, void *workspace,
+                               size_t workspace_bytes, void *stream, double min_ms, double *ms, char *err)
+{
+    if (!d || !ms) { set_err(err, "NULL descriptor / result array"); return EPI_ERR_BAD_ARG; }
+    epi_batch_desc s = *d;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ev[i]);
+    auto done = [&](int rc) { for (auto &x : ev) if (x) (void)hipEventDestroy(x); return rc; };
+    if (e != hipSuccess) return done(hip_fail(err, e, "hipEventCreate"));
+    const int phases[3] = {1, 3, 4};
+    double acc[3] = {0.0, 0.0, 0.0}, total = 0.0;
+    int rounds = 0;
+    for (int r = -1; r < 4096 && (r < 1 || total < min_ms); r++) {       // r = -1: the untimed round
+        (void)hipEventRecord(ev[0], st);
+        for (int q = 0; q < 3; q++) {
+            s.phase = phases[q];
+            const int rc = epi_ekf_run_device(&s, in, out, workspace, workspace_bytes, stream, err);
+            if (rc != EPI_OK) { (void)hipStreamSynchronize(st); return done(rc); }
+            (void)hipEventRecord(ev[q + 1], st);
+        }
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return done(hip_fail(err, e, "kernel execution"));
+        if (r < 0) continue;
+        for (int q = 0; q < 3; q++) {
+            float t = 0.0f;
+            (void)hipEventElapsedTime(&t, ev[q], ev[q + 1]);
+            acc[q] += t; total += t;
+        }
+        rounds++;
+    }
+    for (int q = 0; q < 3; q++) ms[q] = acc[q] / (double)rounds;
+    return done(EPI_OK);
+}
+
 int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err)
 {
     int rc = epi_ekf_validate(d, err);
@@ -1943,6 +1984,7 @@ struct HostCtx {
     int device = -1;
     hipStream_t stream = nullptr;
     char *arena = nullptr; size_t arena_bytes = 0;
+    bool tuned = false;        // the arena is the fastest of several candidates (place_and_run): kept whatever its size
     char *pinned = nullptr;
     ~HostCtx()
     {
@@ -1957,7 +1999,7 @@ struct HostCtx {
         if (bytes <= arena_bytes) return hipSuccess;
         hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess) return e;
-        if (arena) { (void)hipFree(arena); arena = nullptr; arena_bytes = 0; }
+        if (arena) { (void)hipFree(arena); arena = nullptr; arena_bytes = 0; tuned = false; }
         size_t want = bytes + bytes / 4;
         e = hipMalloc((void **)&arena, want);
         if (e != hipSuccess) { (void)hipGetLastError(); want = bytes; e = hipMalloc((void **)&arena, want); }
@@ -1987,7 +2029,7 @@ static HostCtx *ctx_acquire(int device, hipError_t *e)
 // the rest of the process), and a device keeps at most kPoolPerDevice idle contexts
 static void ctx_release(HostCtx *c)
 {
-    if (c->arena_bytes > kArenaKeepBytes) {
+    if (c->arena_bytes > kArenaKeepBytes && !c->tuned) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipFree(c->arena);
         c->arena = nullptr; c->arena_bytes = 0;
@@ -1999,6 +2041,72 @@ static void ctx_release(HostCtx *c)
         if (same < kPoolPerDevice) { g_pool.push_back(c); return; }
     }
     delete c;
+}
+
+// Placement of a host call's arena (epi_batch_desc.placement_tries / epi_prescribe_desc.placement_tries, ABI 6).  Where the
+// allocator puts the ~14 arrays a pass streams concurrently changes the forward kernel's and the smoother's time by 5-15 %
+// (which PHYSICAL pages the allocation got: DESIGN.md 4, "Placement"); it is a property of the allocation and a host-pointer
+// caller never sees the allocation.  When a call has to allocate a NEW arena and asks for `tries` > 1: the call's own kernels
+// are run once untimed (clocks, code objects), then timed on up to `tries` candidate arenas, each allocated while the earlier
+// ones are held (so that other memory is handed out) and each for at least ~15 ms of kernels; the fastest is kept -- with the
+// complete results of its last run in it, nothing is computed again -- and stays with the pooled context whatever its size
+// (epi_host_pool_release frees it).  compute(base, ev0, ev1) enqueues upload + kernels for the arena at `base` on the
+// context's stream and records the two events (when given) around the kernels.
+template <class F>
+static int place_and_run(HostCtx *cx, size_t need, int tries, epi_placement_report *rep, F &&compute, char *err)
+{
+    if (rep) memset(rep, 0, sizeof *rep);
+    const bool fresh = need > cx->arena_bytes;
+    hipError_t e = cx->reserve(need);
+    if (e != hipSuccess) return hip_fail(err, e, "device arena");
+    if (tries <= 1 || !fresh) return compute(cx->arena, nullptr, nullptr);
+    if (tries > EPI_PLACEMENT_MAX_TRIES) tries = EPI_PLACEMENT_MAX_TRIES;
+    int rc = compute(cx->arena, nullptr, nullptr);
+    if (rc != EPI_OK) return rc;
+    if ((e = hipStreamSynchronize(cx->stream)) != hipSuccess) return hip_fail(err, e, "kernel execution (placement warm-up)");
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if ((e = hipEventCreate(&ev0)) != hipSuccess || (e = hipEventCreate(&ev1)) != hipSuccess) {
+        if (ev0) (void)hipEventDestroy(ev0);
+        return hip_fail(err, e, "hipEventCreate");
+    }
+    struct Cand { char *p; size_t bytes; float ms; };
+    std::vector<Cand> cands;
+    for (int i = 0; i < tries && rc == EPI_OK; i++) {
+        Cand c{cx->arena, cx->arena_bytes, 0.0f};
+        if (i > 0) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + need / 16) { (void)hipGetLastError(); break; }
+            if (hipMalloc((void **)&c.p, need) != hipSuccess) { (void)hipGetLastError(); break; }
+            c.bytes = need;
+        }
+        float acc = 0.0f;
+        int n = 0;
+        do {
+            rc = compute(c.p, ev0, ev1);
+            if (rc != EPI_OK) break;
+            if ((e = hipStreamSynchronize(cx->stream)) != hipSuccess) { rc = hip_fail(err, e, "kernel execution (placement try)"); break; }
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, ev0, ev1);
+            acc += ms; n++;
+        } while (acc < 15.0f && n < 64);
+        c.ms = n ? acc / (float)n : 0.0f;
+        cands.push_back(c);
+    }
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    size_t best = 0;
+    for (size_t i = 1; i < cands.size(); i++)
+        if (rc == EPI_OK && cands[i].ms < cands[best].ms) best = i;
+    if (rc != EPI_OK) best = 0;                       // an error: back to the first arena, the others are freed
+    (void)hipStreamSynchronize(cx->stream);
+    for (size_t i = 0; i < cands.size(); i++)
+        if (i != best) (void)hipFree(cands[i].p);
+    if (!cands.empty()) { cx->arena = cands[best].p; cx->arena_bytes = cands[best].bytes; }
+    cx->tuned = rc == EPI_OK && cands.size() > 1;
+    if (rep && rc == EPI_OK) {
+        rep->tries = (int32_t)cands.size(); rep->chosen = (int32_t)best;
+        for (size_t i = 0; i < cands.size(); i++) rep->ms[i] = cands[i].ms;
+    }
+    return rc;
 }
 
 // The arrays of one host call on one context: every array is `rows` rows of which this call moves a strided piece
@@ -2093,9 +2201,79 @@ struct HostIO {
                     for (size_t r = 0; r < p.rows; r++) memcpy(p.dst + r * p.pitch, cx->pinned + p.off + r * p.width, p.width);
             return hipSuccess;
         }
+        // Large pieces into memory the caller has never touched (a MEX gateway's freshly created outputs, np.empty) would be
+        // faulted in page by page under the copy, by ONE thread inside the driver's pinning call: 14-17 GB/s instead of the
+        // 33-52 GB/s resident pages reach (profiles/r06/host_calls.json).  A helper thread therefore populates the destination
+        // of piece k + 1 on several threads (populate_pages) while piece k is on the wire; the copy of a piece is issued when
+        // its pages are there.  Resident pages cost a page-table walk.
+        std::vector<const Piece *> todo;
+        size_t big = 0;
         for (auto &p : outs)
-            if (p.dst && (e = move((char *)base + p.off, p, false, cx->stream)) != hipSuccess) return e;
+            if (p.dst) { todo.push_back(&p); if (span_bytes(p) >= kPopulateMinBytes) big++; }
+        if (big == 0) {
+            for (const Piece *p : todo)
+                if ((e = move((char *)base + p->off, *p, false, cx->stream)) != hipSuccess) return e;
+            return hipStreamSynchronize(cx->stream);
+        }
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t ready = 0;                      // pieces [0, ready) are populated
+        std::thread helper([&] {
+            for (size_t k = 0; k < todo.size(); k++) {
+                if (span_bytes(*todo[k]) >= kPopulateMinBytes) populate_pages(todo[k]->dst, span_bytes(*todo[k]), dense(*todo[k]));
+                { std::lock_guard<std::mutex> lk(mu); ready = k + 1; }
+                cv.notify_one();
+            }
+        });
+        e = hipSuccess;
+        for (size_t k = 0; k < todo.size() && e == hipSuccess; k++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready > k; }); }
+            e = move((char *)base + todo[k]->off, *todo[k], false, cx->stream);
+        }
+        helper.join();
+        if (e != hipSuccess) return e;
         return hipStreamSynchronize(cx->stream);
+    }
+    // bytes of the caller's array a piece spans (a strided piece: first row's start to last row's end, gaps included -- they
+    // belong to the same array)
+    static size_t span_bytes(const Piece &p) { return p.rows ? (p.rows - 1) * p.pitch + p.width : 0; }
+    static constexpr size_t kPopulateMinBytes = (size_t)8 << 20;
+    // Make [p, p + bytes) resident and writable WITHOUT changing its contents: madvise(MADV_POPULATE_WRITE) per slice on up to
+    // eight threads (page-table population scales with threads; one thread zeroes fresh pages at ~10 GB/s), falling back to
+    // writing a byte of every page back to itself where the kernel does not know the advice (< 5.14; dense pieces only).
+    static void populate_pages(char *p, size_t bytes, bool whole)
+    {
+        const size_t page = 4096;
+        const uintptr_t a0 = (uintptr_t)p & ~(uintptr_t)(page - 1), a1 = ((uintptr_t)p + bytes + page - 1) & ~(uintptr_t)(page - 1);
+        const size_t pages = (a1 - a0) / page;
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nt = bytes / ((size_t)16 << 20) + 1;
+        const size_t cap = hw >= 16 ? 12 : (hw >= 4 ? hw / 2 : 1);
+        if (nt > cap) nt = cap;
+        // huge pages where the system grants them on request: 512 times fewer faults, the population is then bound by zeroing
+        if (a1 - a0 >= ((size_t)4 << 20)) (void)madvise((void *)a0, a1 - a0, MADV_HUGEPAGE);
+        auto slice = [=](size_t i) {
+            const uintptr_t b = a0 + pages * i / nt * page, e = a0 + pages * (i + 1) / nt * page;
+            if (e <= b) return;
+#ifdef MADV_POPULATE_WRITE
+            if (madvise((void *)b, e - b, MADV_POPULATE_WRITE) == 0) return;
+#else
+            if (madvise((void *)b, e - b, 23) == 0) return;
+#endif
+            // (a strided piece's gaps are other blocks' columns, which another device's copy may be writing right now: no
+            // write-back there.)  The pages at the two ends may hold bytes outside [p, p + bytes): the byte touched is inside
+            if (!whole) return;
+            for (uintptr_t q = b; q < e; q += page) {
+                uintptr_t t = q < (uintptr_t)p ? (uintptr_t)p : q;
+                if (t >= (uintptr_t)p + bytes) break;
+                volatile char *c = (volatile char *)t;
+                *c = *c;
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < nt; i++) th.emplace_back(slice, i);
+        slice(0);
+        for (auto &t : th) t.join();
     }
 };
 
@@ -2191,29 +2369,41 @@ static int run_host_block(HostCtx *cx, const epi_batch_desc *d0, const epi_input
     dmax.exact_nonfinite = watch ? 1 : -1;           // the workspace is sized for the second pass
     const size_t wsb = epi_ekf_workspace_bytes(&dmax);
     const size_t o_ws = io.reserve(wsb);
-    hipError_t e = cx->reserve(io.off + 256);
-    if (e != hipSuccess) return hip_fail(err, e, "device arena");
-    char *base = cx->arena;
-    din.x_series = in->x_series ? (const int32_t *)(base + o_xs) : nullptr;
-    din.u_series = in->u_series ? (const int32_t *)(base + o_us) : nullptr;
-    din.x = (const double *)(base + o_x); din.u = (const double *)(base + o_u);
-    din.R_series = d.r_mode == 1 ? (const double *)(base + o_rs) : nullptr;
-    din.R_scalar = d.r_mode == 1 ? nullptr : (const double *)(base + o_rc);
-    din.prm = (const double *)(base + o_prm);
-    din.s_init = (const double *)(base + o_si); din.Ps_init = (const double *)(base + o_pi);
-    din.s_final = (const double *)(base + o_sf); din.Ps_final = (const double *)(base + o_pf);
-    din.Q = (const double *)(base + o_q);
-    {
+    hipError_t e = hipSuccess;
+    // the device-side view of the call for the arena at `base`
+    auto bind = [&](char *base) {
+        din.x_series = in->x_series ? (const int32_t *)(base + o_xs) : nullptr;
+        din.u_series = in->u_series ? (const int32_t *)(base + o_us) : nullptr;
+        din.x = (const double *)(base + o_x); din.u = (const double *)(base + o_u);
+        din.R_series = d.r_mode == 1 ? (const double *)(base + o_rs) : nullptr;
+        din.R_scalar = d.r_mode == 1 ? nullptr : (const double *)(base + o_rc);
+        din.prm = (const double *)(base + o_prm);
+        din.s_init = (const double *)(base + o_si); din.Ps_init = (const double *)(base + o_pi);
+        din.s_final = (const double *)(base + o_sf); din.Ps_final = (const double *)(base + o_pf);
+        din.Q = (const double *)(base + o_q);
         size_t k = 0;
         for (auto &o : olist) { if (o_out[k] != (size_t)-1) *o.dev = (double *)(base + o_out[k]); k++; }
+        if (o_rank != (size_t)-1) dout.pinv_rank = (int32_t *)(base + o_rank);
+        if (o_stat != (size_t)-1) dout.status = (int32_t *)(base + o_stat);
+    };
+    // upload + kernels (place_and_run may call this for several candidate arenas; ev0 / ev1 bracket the kernels).  From the
+    // upload on, copies that read the caller's arrays / the pinned buffer may be in flight: every error return waits for the
+    // stream first, so that neither is touched after the call has returned
+    auto compute = [&](char *base, hipEvent_t ev0, hipEvent_t ev1) -> int {
+        bind(base);
+        if ((e = io.upload(cx, base)) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "upload"); }
+        if (ev0) (void)hipEventRecord(ev0, cx->stream);
+        const int rc = epi_ekf_run_device(&d, &din, &dout, wsb ? base + o_ws : nullptr, wsb, cx->stream, err);
+        if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
+        if (ev1) (void)hipEventRecord(ev1, cx->stream);
+        return EPI_OK;
+    };
+    {
+        const int rc = place_and_run(cx, io.off + 256, d0->placement_tries, lo == 0 ? out->placement : nullptr, compute, err);
+        if (rc != EPI_OK) return rc;
     }
-    if (o_rank != (size_t)-1) dout.pinv_rank = (int32_t *)(base + o_rank);
-    if (o_stat != (size_t)-1) dout.status = (int32_t *)(base + o_stat);
-    // from here on copies that read the caller's arrays / the pinned buffer may be in flight: every error return waits
-    // for the stream first, so that neither is touched after the call has returned
-    if ((e = io.upload(cx, base)) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "upload"); }
-    const int rc = epi_ekf_run_device(&d, &din, &dout, wsb ? base + o_ws : nullptr, wsb, cx->stream, err);
-    if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
+    char *base = cx->arena;
+    bind(base);
     if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download");
     if (watch) {
         bool any = false;
@@ -2417,15 +2607,14 @@ static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_
     const size_t o_j0 = io.add_out(out->J0, 1, 8, Bfull, c0, Bd), o_j1 = io.add_out(out->J1, 1, 8, Bfull, c0, Bd);
     const size_t o_of = io.add_out(out->on_front, 1, 4, Bfull, c0, Bd), o_io = io.add_out(out->i_opt, 1, 4, R, r0, Rd);
     const size_t o_uo = io.add_out(out->u_opt, T * n, 8, R, r0, Rd), o_so = io.add_out(out->S_opt, T * 6, 8, R, r0, Rd);
-    epi_outputs dout{};
-    struct O { uint32_t bit; double *host; double **dev; size_t rows; };
+    struct O { uint32_t bit; double *host; double *epi_outputs::*dev; size_t rows; };
     const epi_outputs &ex = out->extras;
-    O olist[] = {{EPI_OUT_U_OPT, ex.u_opt, &dout.u_opt, T * n}, {EPI_OUT_U_OPT_SMOOTH, ex.u_opt_smooth, &dout.u_opt_smooth, T * n},
-                 {EPI_OUT_S_MINUS, ex.S_MINUS, &dout.S_MINUS, T * 6}, {EPI_OUT_S_PLUS, ex.S_PLUS, &dout.S_PLUS, T * 6},
-                 {EPI_OUT_S_SMOOTH, ex.S_SMOOTH, &dout.S_SMOOTH, T * 6}, {EPI_OUT_P_MINUS, ex.P_MINUS, &dout.P_MINUS, T * 36},
-                 {EPI_OUT_P_PLUS, ex.P_PLUS, &dout.P_PLUS, T * 36}, {EPI_OUT_P_SMOOTH, ex.P_SMOOTH, &dout.P_SMOOTH, T * 36},
-                 {EPI_OUT_K_GAIN, ex.K_GAIN, &dout.K_GAIN, T * 6}, {EPI_OUT_INNOVATIONS, ex.innovations, &dout.innovations, T},
-                 {EPI_OUT_RHO, ex.rho, &dout.rho, T}};
+    O olist[] = {{EPI_OUT_U_OPT, ex.u_opt, &epi_outputs::u_opt, T * n}, {EPI_OUT_U_OPT_SMOOTH, ex.u_opt_smooth, &epi_outputs::u_opt_smooth, T * n},
+                 {EPI_OUT_S_MINUS, ex.S_MINUS, &epi_outputs::S_MINUS, T * 6}, {EPI_OUT_S_PLUS, ex.S_PLUS, &epi_outputs::S_PLUS, T * 6},
+                 {EPI_OUT_S_SMOOTH, ex.S_SMOOTH, &epi_outputs::S_SMOOTH, T * 6}, {EPI_OUT_P_MINUS, ex.P_MINUS, &epi_outputs::P_MINUS, T * 36},
+                 {EPI_OUT_P_PLUS, ex.P_PLUS, &epi_outputs::P_PLUS, T * 36}, {EPI_OUT_P_SMOOTH, ex.P_SMOOTH, &epi_outputs::P_SMOOTH, T * 36},
+                 {EPI_OUT_K_GAIN, ex.K_GAIN, &epi_outputs::K_GAIN, T * 6}, {EPI_OUT_INNOVATIONS, ex.innovations, &epi_outputs::innovations, T},
+                 {EPI_OUT_RHO, ex.rho, &epi_outputs::rho, T}};
     std::vector<size_t> o_ex;
     for (auto &o : olist) {
         if ((pd->out_mask & o.bit) && !o.host) { set_err(err, "extras: output selected but NULL"); return EPI_ERR_BAD_ARG; }
@@ -2437,11 +2626,13 @@ static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_
     const size_t o_ss = ((pd->out_mask & EPI_OUT_S_SMOOTH) || !out->S_opt) ? (size_t)-1 : io.reserve(T * 6 * Bp * 8);
     const size_t wsb = epi_ekf_workspace_bytes(&d);
     const size_t o_ws = io.reserve(wsb);
-    hipError_t e = cx->reserve(io.off + 256);
-    if (e != hipSuccess) return hip_fail(err, e, "device arena");
-    char *base = cx->arena;
+    hipError_t e = hipSuccess;
+    // upload + kernels for the arena at `base` (place_and_run may call this for several candidate arenas: every call leaves the
+    // complete results in its arena); ev0 / ev1 bracket the kernels
+    auto compute = [&](char *base, hipEvent_t ev0, hipEvent_t ev1) -> int {
     // (as in run_host_block: after upload() every error return waits for the stream)
     if ((e = io.upload(cx, base)) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "upload"); }
+    if (ev0) (void)hipEventRecord(ev0, cx->stream);
     double *chain = (double *)(base + o_chain);
     int32_t *series = (int32_t *)(base + o_ser);
     hipLaunchKernelGGL(sweep_expand, dim3((unsigned)((Bd + 255) / 256), 8), dim3(256), 0, cx->stream, (int)nrows, Rd, (int)P,
@@ -2455,19 +2646,20 @@ static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_
     din.prm = take(EPI_PRM_COUNT); din.s_init = take(6); din.Ps_init = take(36); din.s_final = take(6); din.Ps_final = take(36);
     din.Q = take(36);
     const double *sp = take(EPI_SIM_PRM_COUNT), *j0p = take(1), *j1p = take(1);
+    epi_outputs dd{};
     {
         size_t k = 0;
-        for (auto &o : olist) { if (o_ex[k] != (size_t)-1) *o.dev = (double *)(base + o_ex[k]); k++; }
+        for (auto &o : olist) { if (o_ex[k] != (size_t)-1) dd.*(o.dev) = (double *)(base + o_ex[k]); k++; }
     }
-    if (!dout.u_opt_smooth) dout.u_opt_smooth = (double *)(base + o_uos);
-    if (!dout.S_SMOOTH && out->S_opt) dout.S_SMOOTH = (double *)(base + o_ss);
+    if (!dd.u_opt_smooth) dd.u_opt_smooth = (double *)(base + o_uos);
+    if (!dd.S_SMOOTH && out->S_opt) dd.S_SMOOTH = (double *)(base + o_ss);
     epi_sweep_desc sd{};
     sd.abi_version = EPIEKF_ABI_VERSION; sd.R = Rd; sd.P = (int32_t)P; sd.t_hist = pd->t_hist;
-    rc = epi_sweep_run_device(&d, &din, &dout, wsb ? base + o_ws : nullptr, wsb, &sd, sp, j0p, j1p, (double *)(base + o_j0),
+    rc = epi_sweep_run_device(&d, &din, &dd, wsb ? base + o_ws : nullptr, wsb, &sd, sp, j0p, j1p, (double *)(base + o_j0),
                               (double *)(base + o_j1), (int32_t *)(base + o_of), (int32_t *)(base + o_io), cx->stream, err);
     if (rc != EPI_OK) { (void)hipStreamSynchronize(cx->stream); return rc; }
     struct G { double *host; const double *src; size_t off; int rows; };
-    const G gs[] = {{out->u_opt, dout.u_opt_smooth, o_uo, (int)n}, {out->S_opt, dout.S_SMOOTH, o_so, 6}};
+    const G gs[] = {{out->u_opt, dd.u_opt_smooth, o_uo, (int)n}, {out->S_opt, dd.S_SMOOTH, o_so, 6}};
     for (auto &g : gs) {
         if (!g.host) continue;
         const size_t cnt = T * (size_t)g.rows * (size_t)Rd;
@@ -2475,6 +2667,12 @@ static int prescribe_block(HostCtx *cx, const epi_prescribe_desc *pd, const epi_
                            (int)blk, (int)nblk, (const int32_t *)(base + o_io), g.src, (double *)(base + g.off));
         if ((e = hipGetLastError()) != hipSuccess) { (void)hipStreamSynchronize(cx->stream); return hip_fail(err, e, "sweep_gather_opt launch"); }
     }
+    if (ev1) (void)hipEventRecord(ev1, cx->stream);
+    return EPI_OK;
+    };
+    rc = place_and_run(cx, io.off + 256, pd->placement_tries, r0 == 0 ? out->placement : nullptr, compute, err);
+    if (rc != EPI_OK) return rc;
+    char *base = cx->arena;
     if ((e = io.download(cx, base)) != hipSuccess) return hip_fail(err, e, "kernel execution / download");
     return EPI_OK;
 }
@@ -2487,6 +2685,7 @@ int epi_sweep_prescribe_host(const epi_prescribe_desc *d, const epi_prescribe_in
     if (d->P > 8192) { set_err(err, "more than 8192 points per region"); return EPI_ERR_UNSUPPORTED; }
     if (d->t_hist < 1 || d->t_hist >= d->T) { set_err(err, "t_hist must leave at least one horizon day: 1 <= t_hist < T"); return EPI_ERR_BAD_ARG; }
     if (d->out_mask & ~(uint32_t)EPI_OUT_ALL) { set_err(err, "unknown bits in out_mask"); return EPI_ERR_BAD_ARG; }
+    if (d->placement_tries < 0 || d->placement_tries > EPI_PLACEMENT_MAX_TRIES) { set_err(err, "placement_tries must be 0 .. EPI_PLACEMENT_MAX_TRIES"); return EPI_ERR_BAD_ARG; }
     int rc = multi_devices_ok(n_devices, device_ids, err);
     if (rc != EPI_OK) return rc;
     const int per = (d->R + n_devices - 1) / n_devices;

@@ -20,19 +20,21 @@ def _f(a, keep):
 
 
 def sweep_prescribe(x, u, R_series, region, eps, sp, J0_prefix, J1_prefix, t_hist, L_win=21, order=1, obs_type="NEWCASES",
-                    devices=(0,), extras=(), shape=0, time_pipe=0, want_S=True):
+                    devices=(0,), extras=(), shape=0, time_pipe=0, want_S=True, placement_tries=0):
     """epi_sweep_prescribe_host: the cost-weight sweep of ALL regions (TrainPredictPrescribeNPI.m:421-493, 624-633).
 
     x, R_series [T, R]; u [T, n, R]; region: dict prm [61, R], s_init [6, R], Ps_init / s_final(6) / Ps_final / Q [36, R];
     eps [P]; sp [48, R]; J0_prefix, J1_prefix [R].  Returns dict J0, J1 [R, P], on_front bool [R, P], i_opt [R] (0-based),
-    u_opt [T, n, R], S_opt [T, 6, R] and the per-chain extras named in `extras` ([T, rows, R * P])."""
+    u_opt [T, n, R], S_opt [T, 6, R] and the per-chain extras named in `extras` ([T, rows, R * P]).
+    placement_tries > 1 (epi_prescribe_desc.placement_tries): a call that allocates a new device arena keeps the fastest of that
+    many candidates; the report of the first device's block comes back as out["placement"] = {tries, chosen, ms}."""
     keep = []
     T, R = np.shape(x)
     n, P = np.shape(u)[1], len(eps)
     d = _lib.PrescribeDesc()
     d.abi_version, d.R, d.P, d.T, d.t_hist, d.n_npi = _lib.ABI_VERSION, R, P, T, int(t_hist), n
     d.L, d.order, d.obs_type = int(L_win), int(order), L.OBS_IDS.get(obs_type, 99) if isinstance(obs_type, str) else int(obs_type)
-    d.shape, d.time_pipe = int(shape), int(time_pipe)
+    d.shape, d.time_pipe, d.placement_tries = int(shape), int(time_pipe), int(placement_tries)
     ins = _lib.PrescribeInputs()
     ins.x, ins.u, ins.R_series, ins.eps = _f(x, keep), _f(u, keep), _f(R_series, keep), _f(eps, keep)
     for k in ("prm", "s_init", "Ps_init", "s_final", "Ps_final", "Q"):
@@ -53,12 +55,15 @@ def sweep_prescribe(x, u, R_series, region, eps, sp, J0_prefix, J1_prefix, t_his
         ex[name] = np.empty((T, rows[name], R * P) if name in rows else (T, R * P))
         setattr(outs.extras, name, ex[name].ctypes.data)
     d.out_mask = mask
+    rep = _lib.PlacementReport()
+    outs.placement = C.addressof(rep)
     ids = (C.c_int * len(devices))(*devices)
     err = C.create_string_buffer(256)
     rc = _lib.lib().epi_sweep_prescribe_host(C.byref(d), C.byref(ins), C.byref(outs), len(devices), ids, err)
     _lib.check(rc, err)
     out["on_front"] = out["on_front"].astype(bool)
     out.update(ex)
+    out["placement"] = {"tries": int(rep.tries), "chosen": int(rep.chosen), "ms": [float(rep.ms[i]) for i in range(rep.tries)]}
     return out
 
 

@@ -180,6 +180,14 @@ typedef struct epi_batch_desc {
                              walks the list of marked chains); (2 B + 1 + B) more int32 of workspace.  The *_host entry points
                              reach the same result without device-side launches: epi_ekf_run_host[_multi] look at the status
                              words that come back with the outputs and enqueue the second pass only when a chain is marked. */
+    int32_t placement_tries; /* HOST-pointer entry points only (ABI 6; the device-pointer entry points ignore it: their caller owns
+                             the allocation and can compare allocations with epi_ekf_time_stages_device).  Where the allocator
+                             puts the ~14 arrays a pass streams concurrently changes the time of the forward kernel and of the
+                             smoother by 5-15 % -- a property of the allocation, invisible to a caller who hands over host
+                             arrays.  N > 1: when the call has to allocate a NEW device arena, its own kernels are timed on up to
+                             N (<= EPI_PLACEMENT_MAX_TRIES) candidate arenas and the fastest is kept, with the pooled context,
+                             for the calls that follow (epi_host_pool_release frees it); epi_outputs.placement receives the
+                             report.  0 / 1 = off.  Cost: once per arena, ~N + 1 times the call's device time. */
     /* TEST HOOKS (ABI 6; until ABI 5 an environment variable read on every call).  Both are 0 in production: a default-
        constructed descriptor never sets them, nothing else in the library reads process-global state.  They only choose
        code paths that the batch size otherwise chooses, so that small tests reach them; results are identical for every value. */
@@ -200,6 +208,13 @@ typedef struct epi_inputs {
     const double *s_init, *Ps_init, *s_final, *Ps_final, *Q;
 } epi_inputs;
 
+#define EPI_PLACEMENT_MAX_TRIES 8
+typedef struct epi_placement_report {
+    int32_t tries;        /* candidate arenas timed; 0 = none (placement_tries <= 1, or the call reused a pooled arena) */
+    int32_t chosen;       /* the one kept */
+    float ms[EPI_PLACEMENT_MAX_TRIES];   /* device time of the call's kernels on each candidate */
+} epi_placement_report;
+
 typedef struct epi_outputs {
     double *u_opt, *u_opt_smooth;
     double *S_MINUS, *S_PLUS, *S_SMOOTH;
@@ -209,12 +224,20 @@ typedef struct epi_outputs {
     int32_t *pinv_rank;   /* [T][B] rank kept by pinv at smoother step k (-1: not executed / guard) */
     int32_t *status;      /* [B] per-chain flags: bit0 non-finite P_MINUS guard hit (GenericEKF.m:211),
                              bit1 Jacobi sweep cap reached, bits 8.. minimum pinv rank seen */
+    epi_placement_report *placement;   /* host-pointer entry points: what placement_tries > 1 did (may be NULL) */
 } epi_outputs;
 
 /* ---- EKF / EKS ---------------------------------------------------------- */
 int epi_model_dim(int model);                                   /* 3, 6 or -1 */
 int epi_ekf_validate(const epi_batch_desc *d, char *err);       /* descriptor checks only, no GPU */
 size_t epi_ekf_workspace_bytes(const epi_batch_desc *d);        /* device scratch a run needs */
+/* Synchronous: (forward + monitor, pinv grid, smoother) milliseconds -- ms[3] -- of this call on THESE device arrays, enqueued
+ * stage by stage between HIP events on `stream`, averaged over as many rounds as fill `min_ms` of device time after one untimed
+ * round.  For comparing ALLOCATIONS: the same arrays give the same times run after run, another allocation of the same arrays
+ * may be 5-15 % slower (where its physical pages fall); a caller that will run many passes times one, allocates again while
+ * holding the first, and keeps the faster (what placement_tries does for the host-pointer entry points). */
+int epi_ekf_time_stages_device(const epi_batch_desc *d, const epi_inputs *in, const epi_outputs *out, void *workspace,
+                               size_t workspace_bytes, void *stream, double min_ms, double *ms, char *err);
 /* Synchronous: inspects Ps_init / Q (device pointers) and reports in *fast_ok whether path_hint = 1 is valid. */
 int epi_ekf_precheck_device(const epi_batch_desc *d, const epi_inputs *in, void *stream, int *fast_ok, char *err);
 
@@ -379,6 +402,7 @@ typedef struct epi_prescribe_desc {
     int32_t n_npi, L, order, obs_type;
     uint32_t out_mask;       /* epi_out bits of the per-chain extras (0 = none) */
     int32_t shape, time_pipe;/* as in epi_batch_desc (0 = let the library decide) */
+    int32_t placement_tries; /* as in epi_batch_desc: N > 1 = a new device arena is the fastest of up to N candidates */
 } epi_prescribe_desc;
 typedef struct epi_prescribe_inputs {
     const double *x, *u, *R_series;
@@ -391,6 +415,7 @@ typedef struct epi_prescribe_outputs {
     int32_t *on_front, *i_opt;
     double *u_opt, *S_opt;
     epi_outputs extras;
+    epi_placement_report *placement;   /* what placement_tries > 1 did on the first device's block (may be NULL) */
 } epi_prescribe_outputs;
 int epi_sweep_prescribe_host(const epi_prescribe_desc *d, const epi_prescribe_inputs *in, const epi_prescribe_outputs *out,
                              int n_devices, const int *device_ids, char *err);

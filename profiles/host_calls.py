@@ -34,7 +34,7 @@ ts = []
 for _ in range(5):
     t0 = time.perf_counter(); got = hostapi.sweep_prescribe(*args); ts.append(time.perf_counter() - t0)
 in_mb = sum(np.asarray(v).nbytes for v in (w0.x, w0.u, w0.R_series, sp, *reg.values())) / 1e6
-out_mb = sum(v.nbytes for v in got.values()) / 1e6
+out_mb = sum(v.nbytes for v in got.values() if hasattr(v, "nbytes")) / 1e6
 rep["sweep_prescribe_host_300x250x520"] = {
     "ms_median": 1e3 * float(np.median(ts)), "ms_min": 1e3 * min(ts), "host_to_device_MB": in_mb, "device_to_host_MB": out_mb,
     "region_day_steps": S * P * (T_hist + hor), "steps_per_s": S * P * (T_hist + hor) / float(np.median(ts)),
@@ -65,6 +65,31 @@ for tag, devs in (("one_block", [0]), ("two_blocks_strided", [0, 0])):
     rep["run_host_multi_9375_chains_reduced_outputs_" + tag] = r
     print(json.dumps(r), flush=True)
 
+# all 11 outputs of the 9 375-chain shard (6.2 GB back over PCIe): into arrays the previous call already wrote (resident pages) and into
+# fresh, never-touched ones (np.empty: the pages are faulted in under the copy -- what a MEX gateway's freshly created outputs cost)
+def timed_cold(w, n, **kw):
+    names = [k for k in H.OUT_NAMES]
+    m, n_npi, B, T = w.m, w.n_npi, w.B, w.T
+    rows = {"u_opt": n_npi, "u_opt_smooth": n_npi, "S_MINUS": m, "S_PLUS": m, "S_SMOOTH": m, "P_MINUS": m * m, "P_PLUS": m * m, "P_SMOOTH": m * m, "K_GAIN": m}
+    tc = []
+    for _ in range(n):
+        out = {k: np.empty((T, rows[k], B) if k in rows else (T, B)) for k in names}
+        H.host_call(w, out=out, timing=tc, extras=False, **kw)
+        mb = sum(v.nbytes for v in out.values()) / 1e6
+        del out
+    return {"c_call_ms_median": 1e3 * float(np.median(tc)), "c_call_ms_min": 1e3 * min(tc), "device_to_host_MB": mb,
+            "c_call_GB_per_s_of_outputs": mb / 1e3 / float(np.median(tc))}
+
+
+r = timed(full, 4, extras=False)
+r["note"] = "epi_ekf_run_host, 9 375 chains, ALL 11 outputs, output arrays of the previous call written again (resident pages)"
+rep["run_host_9375_chains_all_outputs_reused_arrays"] = r
+print(json.dumps(r), flush=True)
+r = timed_cold(full, 3)
+r["note"] = "the same into fresh never-touched arrays (np.empty): page faults under the copy"
+rep["run_host_9375_chains_all_outputs_fresh_arrays"] = r
+print(json.dumps(r), flush=True)
+
 two = synth.make_cfg4(2, 250, 400, 120)
 for tag, w in (("B1", two.select(np.array([137]))), ("B250", two.select(np.arange(250)))):
     r = timed(w, 9, extras=False)
@@ -72,5 +97,10 @@ for tag, w in (("B1", two.select(np.array([137]))), ("B250", two.select(np.arang
     r.update({"chains": w.B, "days": w.T, "cpu_oracle_one_thread_ms": 1e3 * t_cpu, "note": "epi_ekf_run_host, all 11 outputs"})
     rep["run_host_" + tag] = r
     print(json.dumps(r), flush=True)
+    if tag == "B250":
+        r = timed_cold(w, 7)
+        r["note"] = "B = 250, all 11 outputs into fresh never-touched arrays"
+        rep["run_host_B250_fresh_arrays"] = r
+        print(json.dumps(r), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "host_calls.json"), "w"), indent=1)

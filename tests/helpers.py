@@ -198,11 +198,12 @@ def lapack_reading_worker(job):
     return out
 
 
-def host_call(w, devices=None, outputs=None, extras=True, shape=0, out=None, timing=None):
+def host_call(w, devices=None, outputs=None, extras=True, shape=0, out=None, timing=None, placement_tries=0, report=None):
     """Workload `w` through the HOST-pointer C ABI (classic layout, numpy arrays [T][rows][B]): epi_ekf_run_host on device
     0, or -- devices = list of device ids -- epi_ekf_run_host_multi with one chain block per entry.  Returns dict of arrays.
     `out`: the dict a previous call returned (its arrays are written again instead of allocating and NaN-filling new ones);
-    `timing`: a list that gets the seconds the C call itself took appended."""
+    `timing`: a list that gets the seconds the C call itself took appended; `placement_tries` / `report` (a list that gets
+    {"tries", "chosen", "ms"} appended): epi_batch_desc.placement_tries and the epi_placement_report the call fills."""
     import ctypes as C
     import time
     from epidemicmodeling_amd import _lib
@@ -219,7 +220,10 @@ def host_call(w, devices=None, outputs=None, extras=True, shape=0, out=None, tim
     d = _lib.make_desc(w.model, B, T, Sx, Su, n_npi, w.L, w.order, w.obs_type, 1 if w.R_series is not None else 0, mask,
                        1 if np.ndim(w.Q) == 3 else 0)
     d.shape = shape
+    d.placement_tries = int(placement_tries)
     ins, outs = _lib.Inputs(), _lib.Outputs()
+    rep = _lib.PlacementReport()
+    outs.placement = C.addressof(rep)
     keep = []
     def ptr(a, dt=np.float64):
         if a is None:
@@ -245,6 +249,8 @@ def host_call(w, devices=None, outputs=None, extras=True, shape=0, out=None, tim
     if timing is not None:
         timing.append(time.perf_counter() - t0)
     _lib.check(rc, err)
+    if report is not None:
+        report.append({"tries": int(rep.tries), "chosen": int(rep.chosen), "ms": [float(rep.ms[i]) for i in range(rep.tries)]})
     return out
 
 
