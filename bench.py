@@ -104,9 +104,9 @@ def make_workload(args, rank):
     return w, name
 
 
-# stage times of the headline workload in the fast placement mode (profiles/r04/bench_distribution.txt, alloc/): a run whose
-# forward stage or smoother is above these ran on an allocation whose arrays collide in the L2
-PLACEMENT_SLOW_MS = {"ekf_fwd": 6.4, "eks_bwd": 7.6}
+# stage times of the headline workload in the fast placement mode (profiles/r06/bench_distribution.txt; r04/alloc/): a run whose
+# forward stage or smoother is above these ran on an allocation whose arrays collide in the L2 ("Placement")
+PLACEMENT_SLOW_MS = {"ekf_fwd": 6.4, "eks_bwd": 7.1}
 
 
 def placement_report(placement, args, ms, wname):
@@ -364,23 +364,24 @@ def main():
     # EPI_BENCH_STAGED=1: every pass -- warm-up included -- is enqueued stage by stage, so that a `rocprofv3 --stats` of the run
     # sees ONE kind of launch per kernel and its averages are the per-kernel durations `roofline` quotes
     staged = os.environ.get("EPI_BENCH_STAGED") == "1"
-    spin_passes = 0
+    spin_passes, spin_ms = 0, 0.0
     if args.spinup_ms > 0:        # set-up: the device at its steady clocks before the warm-up passes (see --spinup-ms)
-        def spin_step():
-            one_step([torch.cuda.Event(enable_timing=True) for _ in range(4)] if staged else None)
+        # passes until the wall clock says so (the first pass after set-up may be cold -- code objects, lazy initialisation --
+        # so the count is not extrapolated from it); with N > 1 the passes contain the gather, so the ranks agree on every
+        # further pass by an all-reduced flag
         t_spin = time.perf_counter()
-        spin_step()
-        torch.cuda.synchronize(dev)
-        est_ms = max((time.perf_counter() - t_spin) * 1e3, 1e-3)
-        spin_passes = max(int(np.ceil(args.spinup_ms / est_ms)) - 1, 0)
-        if world > 1:             # the passes contain the gather: every rank must run the same number of them
-            tn = torch.tensor([spin_passes], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
-            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
-            spin_passes = int(tn.item())
-        for _ in range(spin_passes):
-            spin_step()
-        torch.cuda.synchronize(dev)
-        spin_passes += 1
+        while True:
+            one_step([torch.cuda.Event(enable_timing=True) for _ in range(4)] if staged else None)
+            torch.cuda.synchronize(dev)
+            spin_passes += 1
+            more = (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms
+            if world > 1:
+                tn = torch.tensor([1 if more else 0], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+                more = bool(tn.item())
+            if not more:
+                break
+        spin_ms = (time.perf_counter() - t_spin) * 1e3
     for _ in range(args.warmup):
         one_step([torch.cuda.Event(enable_timing=True) for _ in range(4)] if staged else None)
     torch.cuda.synchronize(dev)
@@ -456,7 +457,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if (strong or world == 1) and args.scaling == "strong" else "weak",
             "vs_baseline": None, "dtype": "f64" if args.storage == "f64" else "f64 arithmetic, f32 storage", "data": "synthetic",
-            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "time_pipe": args.time_pipe, "spinup_ms": args.spinup_ms, "spinup_passes": spin_passes,
+            "config": {"workload": wname, "chains_per_gpu": w.B, "days": w.T, "outputs": args.outputs, "storage": args.storage, "time_pipe": args.time_pipe, "spinup_ms": args.spinup_ms, "spinup_passes": spin_passes, "spinup_ms_actual": round(spin_ms, 1),
                        "lane_block": runner.blk, "shape": ("wave (one wavefront per chain)" if m == 6 else "wave (seven 9-lane chains per wavefront)") if runner.blk == 1 and w.B > 1 else (("quad (4 lanes per chain)" if runner.blk == 16 else ("hex (6 lanes per chain)" if runner.blk == 10 else "lane (1 lane per chain)")) if m == 6 else "lane (1 lane per chain)"),
                        "sweep_chains_total": B_total,
                        "region_day_steps_per_pass_per_gpu": steps_per_pass,
@@ -469,14 +470,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          # what the kernel actually moves (PMC bytes of the committed profile / this run's duration):
-                         # the smoother re-reads S+-, P+-, X, so its HBM throughput is ~2.5x the algorithmic figure
+                         # the smoother reads S+, P+, X back (round 6: no longer S-, P-), ~1.9x the algorithmic figure
                          "traffic_GBs": None if traffic is None else traffic / (ms[dom] * 1e-3) / 1e9,
                          "traffic_frac_of_peak": None if traffic is None else traffic / (ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "measured_copy": copy_bw,     # this box, this process: bytes read + written per second
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes,
-                         "limiter": {"ekf_fwd": "HBM writes (store pattern) + lone-wave latency",
-                                     "eks_pinv": "HBM nearly everywhere (full-rank covariances are inverted from the pivoted Cholesky factor), fp64 VALU issue on the days where ranks 3-5 go through the one-sided Jacobi; SIMD VALU busy 81 % of the kernel's duration, profiles/r04/valu_summary.json",
-                                     "eks_bwd": "lone-wave latency + HBM"}[dom]},
+                         "limiter": {"ekf_fwd": "HBM writes: 32.4 GB at the box's fill rate; a lone wave per SIMD issues 73 % of the time (profiles/r06/valu_summary.json)",
+                                     "eks_pinv": "fp64 VALU issue (SIMD VALU busy 82 % of the kernel's duration, three waves per SIMD) on top of 13.5 GB of traffic; profiles/r06/valu_summary.json",
+                                     "eks_bwd": "instruction issue of a lone wave per SIMD in two rounds (a wave issues 66 % of its cycles, waits for memory 12 %); HBM second (32 GB at 4.8 TB/s); profiles/r06/valu_summary.json"}[dom]},
             "kernels": {**{k + "_ms": v for k, v in ms.items()},
                         **{k + "_GBs": alg[k] * steps_per_pass / (ms[k] * 1e-3) / 1e9 for k in ms},
                         "whole_step_algorithmic_bytes": step_bytes, "whole_step_GBs": step_gbs,

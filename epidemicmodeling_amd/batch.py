@@ -186,7 +186,10 @@ class EkfRunner:
         rest.  One-time set-up cost: a few passes and, transiently, `tries` x the outputs' memory (skipped when that does not
         fit).  The device is brought to its steady clocks first (`spinup_ms` of passes: after idle the first 50-150 ms of work
         run up to 15 % slower, which would make the FIRST try look bad whatever its placement) and every try is timed over at
-        least 15 ms of work.  Returns {"tries": [...ms per try...], "chosen": i}."""
+        least 15 ms of work.  Returns {"tries": [...ms per try...], "chosen": i}.
+        Call it BEFORE anything keeps a reference to `out` / `ws`: when another allocation than the first is kept (`generation`
+        is then incremented), tensors taken from `out` earlier and HIP graphs captured from earlier run() calls still point at
+        memory this runner no longer writes.  A later allocation is kept only if it wins by more than 1 %."""
         import time
         dev = self.dw.device
         if int(tries) > 1 and spinup_ms > 0:
@@ -207,6 +210,9 @@ class EkfRunner:
             log.append({"fwd_ms": f, "pinv_ms": p, "bwd_ms": b, "sum_ms": f + p + b})
             held.append((self.out, self.ws, self._slab))
         best = int(np.argmin([x["sum_ms"] for x in log]))
+        if best != 0 and log[best]["sum_ms"] > 0.99 * log[0]["sum_ms"]:
+            best = 0                      # inside the timing noise: the first allocation stays
+        self.generation = getattr(self, "generation", 0) + (1 if best != 0 else 0)
         self.out, self.ws, self._slab = held[best]
         self._bind()
         del held
@@ -322,26 +328,42 @@ def blocks_side_by_side(buf: torch.Tensor) -> torch.Tensor:
     return buf.movedim(0, -2).reshape(tuple(buf.shape[1:-1]) + (world * per,))
 
 
+_GATHER_BUFS = {}       # (device, dtype, shape of a padded block, world) -> (send block, receive buffer): allocated once per sweep shape
+
+
 def gather_shards_to_root(t: torch.Tensor, B_total: int, group=None, dst: int = 0):
     """Strong-scaling form of the end-of-sweep gather: `t` [..., n_r] holds this rank's block of a chain-minor result whose
     blocks come from shard_chains(B_total, rank, world) -- all of length ceil(B_total / world) except a shorter (possibly
     empty) last one.  Blocks are padded to the common length, gathered to rank `dst` (one message per peer) and
-    reassembled there in chain order; returns the [..., B_total] tensor on `dst`, None elsewhere."""
+    reassembled there in chain order; returns the [..., B_total] tensor on `dst`, None elsewhere.  The padded send block and
+    the receive buffer are allocated on the first call for a shape and reused: a pass costs one copy into the send block
+    (only when the block is short or not contiguous) and the collective, no allocation."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = (B_total + world - 1) // world
-    if t.shape[-1] < per:
-        t = torch.nn.functional.pad(t, (0, per - t.shape[-1]))
-    t = t.contiguous()
-    if dist.get_backend(group) == "nccl":
+    nccl = dist.get_backend(group) == "nccl"
+    if t.shape[-1] == per and t.is_contiguous():
+        send = t
+        key = (t.device, t.dtype, tuple(t.shape), world)
+        if nccl and key not in _GATHER_BUFS:
+            _GATHER_BUFS[key] = (None, torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device))
+    else:
+        shape = tuple(t.shape[:-1]) + (per,)
+        key = (t.device, t.dtype, shape, world)
+        if key not in _GATHER_BUFS or _GATHER_BUFS[key][0] is None:
+            _GATHER_BUFS[key] = (torch.zeros(shape, dtype=t.dtype, device=t.device),
+                                 torch.empty((world,) + shape, dtype=t.dtype, device=t.device) if nccl else None)
+        send = _GATHER_BUFS[key][0]
+        send[..., :t.shape[-1]].copy_(t)          # the padding stays zero
+    if nccl:
         # RCCL: one ncclAllGather of the small per-chain summaries (SURVEY.md 8e: 16 B per chain) -- every rank receives
         # them, rank `dst` uses them.  Issued for every world size, one rank included.
-        buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(buf, t, group=group)
+        buf = _GATHER_BUFS[key][1]
+        dist.all_gather_into_tensor(buf, send, group=group)
         if dist.get_rank(group) != dst:
             return None
         return blocks_side_by_side(buf)[..., :B_total]
-    parts = gather_to_root(t, group=group, dst=dst)
+    parts = gather_to_root(send, group=group, dst=dst)
     if dist.get_rank(group) != dst:
         return None
     return torch.cat([p_.to(t.device) for p_ in parts], dim=-1)[..., :B_total]

@@ -55,7 +55,7 @@
 #define EPI_LANE6_PHASES 1
 #endif
 // the lane blocks these kernels are instantiated for: the balanced waves (balanced_lanes) of batches beyond one round of 64-lane
-// waves -- 40 is the headline's; with 64 lanes the LDS columns of four workgroups would not fit a CU
+// waves -- 40 is the headline's; not 64 (enqueue_bwd says why)
 constexpr bool lane6_block(int blk) { return blk == 40 || blk == 48 || blk == 56; }
 constexpr unsigned kLwRecords = 0x7FFFFFF8u;       // just below 2 GiB: the bounds check includes the scalar offset (ekf_hex.hpp)
 

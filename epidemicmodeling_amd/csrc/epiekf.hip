@@ -90,6 +90,7 @@ struct KArgs {
     int32_t *only_buf;
     int mon_defer;   // 1: this launch does not enqueue ekf_monitor itself (the caller does, later)
     int mon_hoist;   // 1: the packed / quad forward kernels skip the innovation monitor, ekf_monitor replays it (r_mode 1)
+    int mon_scan;    // test hook (epi_batch_desc.test_flags bit 1): the scan kernel ekf_monitor whatever the batch size
     struct F32 { float *u_opt, *u_opt_smooth, *S_MINUS, *S_PLUS, *S_SMOOTH, *P_MINUS, *P_PLUS, *P_SMOOTH, *K_GAIN, *innovations, *rho; } f;
 };
 
@@ -1168,9 +1169,9 @@ static hipError_t launch_monitor(const KArgs &ka, int dev, hipStream_t st)
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
     const int mb = (ka.B + kWave - 1) / kWave;
 #ifndef EPI_MONITOR_PAR_MAX_WAVES
-#define EPI_MONITOR_PAR_MAX_WAVES 1       // use the scan-free grid (ekf_monitor_par) while the batch has at most that many waves per SIMD
+#define EPI_MONITOR_PAR_MAX_WAVES 1       // use the scan-free grid (ekf_monitor_par) while the batch has at most ONE 64-chain wave per SIMD (65 536 chains)
 #endif
-    if (ka.L == 21 && (long)mb <= (long)EPI_MONITOR_PAR_MAX_WAVES * simd_count(dev)) {
+    if (ka.L == 21 && !ka.mon_scan && (long)mb <= (long)EPI_MONITOR_PAR_MAX_WAVES * simd_count(dev)) {
         constexpr int D = 8;
         hipLaunchKernelGGL((ekf_monitor_par<FLIP, 21, D>), dim3(mb, (ka.T + D - 1) / D), dim3(kWave), 0, st, ka, ka.dense_flag);
         return hipGetLastError();
@@ -1378,8 +1379,12 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
         if constexpr (M == 6 && GENERIC) {
             // one lane per chain with fixed descriptors per addressing window (ekf_lane6.hpp): the layout block must be the
             // lanes a workgroup uses, and a compile-time constant
-            if (!done && EPI_LANE6_BWD && !ka.stor && lane6_block(ka.blk) && (long)ka.blk * ka.nblk <= (1L << 20)) {
-                const int lblocks = (ka.B + ka.blk - 1) / ka.blk;
+            // (not for 64-chain blocks: four workgroups' LDS columns would not fit a CU, and where three suffice -- one round of 64-lane
+            // waves, the N = 2 shard of the headline sweep: 37 500 chains -- the kernel measured 3.84 against eks_bwd_sym's 3.5 ms:
+            // such a batch is not issue-bound, profiles/r06/ab_n2_shard.txt)
+            const int lblocks = (ka.B + ka.blk - 1) / ka.blk;
+            const bool l6_ok = lane6_block(ka.blk);
+            if (!done && EPI_LANE6_BWD && !ka.stor && l6_ok && (long)ka.blk * ka.nblk <= (1L << 20)) {
 #if EPI_LANE6_BWD == 3
                 if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6d<FLIP, 40>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
 #else
@@ -1707,7 +1712,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->exact_nonfinite < -1 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 (default: on), 1 (on) or -1 (off)"); return EPI_ERR_BAD_ARG; }
     if (d->placement_tries < 0 || d->placement_tries > EPI_PLACEMENT_MAX_TRIES) { set_err(err, "placement_tries must be 0 .. EPI_PLACEMENT_MAX_TRIES"); return EPI_ERR_BAD_ARG; }
     if (d->test_window < 0 || d->test_window == 1) { set_err(err, "test_window must be 0 (production) or >= 2"); return EPI_ERR_BAD_ARG; }
-    if (d->test_flags < 0 || d->test_flags > 1) { set_err(err, "test_flags must be 0 (production) or 1"); return EPI_ERR_BAD_ARG; }
+    if (d->test_flags < 0 || d->test_flags > 3) { set_err(err, "test_flags must be 0 (production) .. 3"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;
@@ -1769,6 +1774,7 @@ static int run_device_impl(const epi_batch_desc *d, const epi_inputs *in, const 
     ka.quad = shape_of(d, dev) == EPI_SHAPE_QUAD ? 1 : 0;
     ka.wave = shape_of(d, dev) == EPI_SHAPE_WAVE ? 1 : 0;
     ka.hex = shape_of(d, dev) == EPI_SHAPE_HEX ? 1 : 0;
+    ka.mon_scan = (d->test_flags >> 1) & 1;
     ka.hexw = d->test_window;      // test hook (0 in production): days per addressing window, see epi_batch_desc.test_window
     ka.stor = f32 ? 1 : 0;
     ka.bk_from = d->T - 2; ka.bk_to = 0;

@@ -196,7 +196,9 @@ typedef struct epi_batch_desc {
                              (>= 2) instead of as many as fit 2 GiB.  It can only SHORTEN the window. */
     int32_t test_flags;   /* bit 0: a full call in the hex shape takes the reverse-time pipeline (pinv grids of the earlier days
                              beside the smoother's first launches) whatever the batch size and day count, which otherwise
-                             engages beyond 768 hex wavefronts and 128 days only. */
+                             engages beyond 768 hex wavefronts and 128 days only.
+                             bit 1: the innovation monitor's scan kernel (ekf_monitor) replays rho whatever the batch size; below
+                             65 537 chains the scan-free grid (ekf_monitor_par) otherwise does. */
 } epi_batch_desc;
 
 typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3, EPI_SHAPE_HEX = 4 } epi_shape;
