@@ -357,13 +357,15 @@ def main():
             gather_log["host_s"] += time.perf_counter() - tg
 
     gather_log = {"on": False, "events": [], "host_s": 0.0}
-    one_step()
+    # EPI_BENCH_STAGED=1: every pass -- the very first and the warm-up included -- is enqueued stage by stage, so that a
+    # `rocprofv3 --stats` of the run sees ONE kind of launch per kernel and its averages are the per-kernel durations `roofline`
+    # quotes (round 5's CSV held one overlapped call: its monitor launch, beside the pinv grid and the smoother on the helper
+    # stream, spans both -- 9.45 ms against 0.67 alone; profiles/r06/monitor_outlier.txt)
+    staged = os.environ.get("EPI_BENCH_STAGED") == "1"
+    one_step([torch.cuda.Event(enable_timing=True) for _ in range(4)] if staged else None)
     torch.cuda.synchronize(dev)
     if score:
         prepare_scoring()
-    # EPI_BENCH_STAGED=1: every pass -- warm-up included -- is enqueued stage by stage, so that a `rocprofv3 --stats` of the run
-    # sees ONE kind of launch per kernel and its averages are the per-kernel durations `roofline` quotes
-    staged = os.environ.get("EPI_BENCH_STAGED") == "1"
     spin_passes, spin_ms = 0, 0.0
     if args.spinup_ms > 0:        # set-up: the device at its steady clocks before the warm-up passes (see --spinup-ms)
         # passes until the wall clock says so (the first pass after set-up may be cold -- code objects, lazy initialisation --

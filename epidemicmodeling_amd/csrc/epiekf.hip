@@ -1169,7 +1169,9 @@ static hipError_t launch_monitor(const KArgs &ka, int dev, hipStream_t st)
     const size_t shm = (size_t)4 * ka.L * kWave * sizeof(double);
     const int mb = (ka.B + kWave - 1) / kWave;
 #ifndef EPI_MONITOR_PAR_MAX_WAVES
-#define EPI_MONITOR_PAR_MAX_WAVES 1       // use the scan-free grid (ekf_monitor_par) while the batch has at most ONE 64-chain wave per SIMD (65 536 chains)
+#define EPI_MONITOR_PAR_MAX_WAVES 2       // use the scan-free grid (ekf_monitor_par) while the batch has at most TWO 64-chain waves per SIMD (131 072 chains;
+                                          // round 6: the headline's 75 000 chains included -- forward stage + monitor 5.45-5.6 against 5.8-6.3 ms, the pass
+                                          // 0.3-0.5 ms shorter in each of four alternating runs, profiles/r06/ab_monitor_par.txt; round 5 had it at one)
 #endif
     if (ka.L == 21 && !ka.mon_scan && (long)mb <= (long)EPI_MONITOR_PAR_MAX_WAVES * simd_count(dev)) {
         constexpr int D = 8;
@@ -1633,7 +1635,11 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         if ((e = launch_monitor<FLIP>(ka, L.dev, h->stream)) != hipSuccess) return e;
         helper_busy = true;
     }
-    if (L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2 && !ka.wave) {
+    // (Not for a one-lane batch that runs in ROUNDS of resident waves -- more 64-chain waves than SIMDs, the headline sweep: every
+    // SIMD is taken by a 512-register wave, the tail finds no room beside the smoother and a second launch costs the smoother a
+    // second pair of rounds: 15.1-15.9 against 15.6-16.2 ms per pass over four alternating runs, profiles/r06/ab_monitor_par.txt.)
+    const bool in_rounds = !ka.hex && !ka.quad && !ka.wave && fwd_waves > (long)simd_count(L.dev);
+    if (!in_rounds && L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2 && !ka.wave) {
         KArgs kb = ka;
         kb.bk_from = T - 2; kb.bk_to = L.tail->t_hist;              // the horizon days
         if ((e = enqueue_bwd<M, FLIP, GENERIC>(kb, L, st)) != hipSuccess) return e;

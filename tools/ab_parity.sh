@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6: parity of one build of the library on the lane6 tests + the full-size headline test, then A/B of builds
-# usage: tools/r6_ab2.sh "parity_lib.so ..." "ab libs" REPS [bench args]
+# bit-exactness of A/B builds of the library (files under ab/) on the tests that reach the headline's kernels, then the A/B itself
+# on one box (tools/ab_variants.sh):   tools/ab_parity.sh "parity_lib.so ..." "ab libs" REPS [bench args]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
 for L in $1; do

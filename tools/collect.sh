@@ -33,8 +33,8 @@ case $STAGE in
     python3 bench.py --no-cpu-baseline --regions 75 --eps 125 > $O/bench_shard9375.json 2>/dev/null && echo shard ok ;;
   stats)
     cd /tmp && export TMPDIR=/tmp
-    EPI_BENCH_STAGED=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats75k -o bench -- python3 $R/bench.py --no-cpu-baseline > $O/bench_cfg4_staged_under_rocprof.json 2>/dev/null && echo stats75k
-    EPI_BENCH_STAGED=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats9375 -o bench -- python3 $R/bench.py --no-cpu-baseline --regions 75 --eps 125 > $O/bench_shard9375_staged_under_rocprof.json 2>/dev/null && echo stats9375
+    EPI_BENCH_STAGED=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats75k -o bench -- python3 $R/bench.py --no-cpu-baseline --placement-tries 1 > $O/bench_cfg4_staged_under_rocprof.json 2>/dev/null && echo stats75k
+    EPI_BENCH_STAGED=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats9375 -o bench -- python3 $R/bench.py --no-cpu-baseline --placement-tries 1 --regions 75 --eps 125 > $O/bench_shard9375_staged_under_rocprof.json 2>/dev/null && echo stats9375
     cd $R
     cp $(find $O/stats75k -name "*kernel_stats.csv" | head -1) $O/bench_cfg4_staged_kernel_stats.csv
     cp $(find $O/stats9375 -name "*kernel_stats.csv" | head -1) $O/bench_shard9375_staged_kernel_stats.csv
