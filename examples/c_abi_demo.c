@@ -49,8 +49,18 @@ int main(int argc, char **argv)
     out.P_MINUS = calloc(nP, 8); out.P_PLUS = calloc(nP, 8); out.P_SMOOTH = calloc(nP, 8);
     out.K_GAIN = calloc(nS, 8); out.innovations = calloc(T, 8); out.rho = calloc(T, 8);
     char err[256] = {0};
+    /* placement (ABI 6): the first call of a size allocates the device arena -- let it be the fastest of three candidates;
+       the report says what was tried, the next call finds the arena with the pooled context */
+    epi_placement_report rep;
+    d.placement_tries = 3; out.placement = &rep;
     int rc = epi_ekf_run_host(&d, &in, &out, 0, err);
     if (rc != EPI_OK) { fprintf(stderr, "epi_ekf_run_host: %d (%s) %s\n", rc, epi_status_string(rc), err); return 1; }
+    printf("placement: %d arenas tried, kept #%d:", rep.tries, rep.chosen);
+    for (int i = 0; i < rep.tries; i++) printf(" %.3f ms", rep.ms[i]);
+    printf("\n");
+    if (rep.tries != 3 || rep.chosen < 0 || rep.chosen >= 3) return 1;
+    rc = epi_ekf_run_host(&d, &in, &out, 0, err);
+    if (rc != EPI_OK || rep.tries != 0) { fprintf(stderr, "second call: rc %d, %d tries (expected none: pooled arena)\n", rc, rep.tries); return 1; }
 
     /* error behaviour mirrors the reference: order = 3 -> 'Undefined order' */
     d.order = 3;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The default bench and the 9 375-chain shard on N freshly acquired boxes (one gpurun call each; run from the build container):
 #   tools/bench_distribution.sh N OUTFILE
-N=${1:-8}; OUT=${2:-profiles/r05/bench_distribution.txt}
+N=${1:-8}; OUT=${2:-profiles/r06/bench_distribution.txt}
 cd /root/repo
 mkdir -p gpurun_out/dist
 {
