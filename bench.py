@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="f32 = BASELINE config 5's fp32: outputs STORED as float32, arithmetic and the smoother's inputs fp64 "
                          "(SURVEY.md 0: fp32 covariance arithmetic is not viable at cond(P) up to 1e8)")
-    ap.add_argument("--placement-tries", type=int, default=3,
+    ap.add_argument("--placement-tries", type=int, default=5,
                     help="one-time set-up before the first pass (EkfRunner.tune_placement): time a staged pass on this many "
                          "allocations of the outputs + workspace and keep the fastest (where the allocator puts the ~14 concurrently "
                          "streamed arrays changes a pass by up to 15 %, DESIGN.md 5); 1 = take what the allocator gives")

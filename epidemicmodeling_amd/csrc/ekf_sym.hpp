@@ -324,7 +324,9 @@ __global__ __launch_bounds__(EPI_FWD_LB, (M == 3 && LP == 2) ? EPI_FWD3_WAVES : 
             if (!USD) load_u(a, tn, su, u_nxt);
         }
 
-        store_vec<M>(a.S_MINUS, t, lay, sk_minus);
+        // (fp32 storage, three states: the fp64 S_MINUS is workspace that nobody reads -- eks_bwd_sym<3> recomputes s(k+1|k), the
+        // pinv grid reads P_MINUS only, a later time segment resumes from the hand-over row stored below -- 24 of ~330 bytes a step)
+        if (!(STOR && M == 3)) store_vec<M>(a.S_MINUS, t, lay, sk_minus);
         store_sym<M>(a.P_MINUS, t, lay, Pm, (a.ws_upper & 1) != 0);
         if (STOR) { store_rows_f32<M>(a.f.S_MINUS, t, M, lay, sk_minus); store_sym_f32<M>(a.f.P_MINUS, t, lay, Pm); }
 

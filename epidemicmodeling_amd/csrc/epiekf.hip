@@ -1328,8 +1328,10 @@ static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st)
 }
 
 // backward recursion over smoother steps ka.bk_from ... ka.bk_to (the dense kernels only know the full range)
+// (c0, cn: a chain range -- a multiple of the layout block -- for the fixed-descriptor one-lane smoother; every other kernel
+// takes the whole batch)
 template <int M, int FLIP, int GENERIC>
-static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
+static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st, int c0 = 0, int cn = -1)
 {
     ka.c0 = 0; ka.cn = ka.B;
     ka.lw = balanced_lanes(ka.B, M == 6 ? 1 : 2, L.dev);
@@ -1384,9 +1386,10 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st)
             // (not for 64-chain blocks: four workgroups' LDS columns would not fit a CU, and where three suffice -- one round of 64-lane
             // waves, the N = 2 shard of the headline sweep: 37 500 chains -- the kernel measured 3.84 against eks_bwd_sym's 3.5 ms:
             // such a batch is not issue-bound, profiles/r06/ab_n2_shard.txt)
-            const int lblocks = (ka.B + ka.blk - 1) / ka.blk;
             const bool l6_ok = lane6_block(ka.blk);
             if (!done && EPI_LANE6_BWD && !ka.stor && l6_ok && (long)ka.blk * ka.nblk <= (1L << 20)) {
+                if (cn >= 0) { ka.c0 = c0; ka.cn = cn; }
+                const int lblocks = (ka.cn + ka.blk - 1) / ka.blk;
 #if EPI_LANE6_BWD == 3
                 if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6d<FLIP, 40>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
 #else
@@ -1631,14 +1634,28 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         if (ka.mon_hoist && (ka.rho || ka.f.rho) && (e = fork(st, h->stream)) != hipSuccess) return e;
         if ((e = enqueue_pinv<M>(ka, 0, T - 1, st)) != hipSuccess) return e;
     }
-    if (ka.mon_hoist && (ka.rho || ka.f.rho)) {
+    // A one-lane batch that runs in ROUNDS (more 64-chain waves than SIMDs: the headline sweep) on the fixed-descriptor smoother:
+    // the chains of the smoother's first round of resident waves and the rest are two launches, and the monitor starts between
+    // them -- beside the second launch, whose waves leave SIMDs free (851 waves on 1 024 SIMDs at 75 000 chains), instead of
+    // beside the pinv grid, which is bound by the vector unit and simply takes 0.44 ms longer with the monitor next to it.
+    const bool in_rounds = !ka.hex && !ka.quad && !ka.wave && fwd_waves > (long)simd_count(L.dev);
+    bool mon_late = false;
+    int first_round = 0;
+    if constexpr (M == 6 && GENERIC) {
+#ifndef EPI_MONITOR_LATE
+#define EPI_MONITOR_LATE 1
+#endif
+        first_round = simd_count(L.dev) * ka.blk;
+        mon_late = EPI_MONITOR_LATE && !tp && in_rounds && EPI_LANE6_BWD && !ka.stor && lane6_block(ka.blk) && (long)ka.blk * ka.nblk <= (1L << 20) &&
+                   ka.mon_hoist && (ka.rho || ka.f.rho) && first_round < ka.B;
+    }
+    if (!mon_late && ka.mon_hoist && (ka.rho || ka.f.rho)) {
         if ((e = launch_monitor<FLIP>(ka, L.dev, h->stream)) != hipSuccess) return e;
         helper_busy = true;
     }
     // (Not for a one-lane batch that runs in ROUNDS of resident waves -- more 64-chain waves than SIMDs, the headline sweep: every
     // SIMD is taken by a 512-register wave, the tail finds no room beside the smoother and a second launch costs the smoother a
     // second pair of rounds: 15.1-15.9 against 15.6-16.2 ms per pass over four alternating runs, profiles/r06/ab_monitor_par.txt.)
-    const bool in_rounds = !ka.hex && !ka.quad && !ka.wave && fwd_waves > (long)simd_count(L.dev);
     if (!in_rounds && L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2 && !ka.wave) {
         KArgs kb = ka;
         kb.bk_from = T - 2; kb.bk_to = L.tail->t_hist;              // the horizon days
@@ -1648,6 +1665,13 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         helper_busy = true;
         kb.bk_from = L.tail->t_hist - 1; kb.bk_to = 0;              // the observed days
         if ((e = enqueue_bwd<M, FLIP, GENERIC>(kb, L, st)) != hipSuccess) return e;
+    } else if (mon_late) {
+        if ((e = enqueue_bwd<M, FLIP, GENERIC>(ka, L, st, 0, first_round)) != hipSuccess) return e;
+        if ((e = fork(st, h->stream)) != hipSuccess) return e;
+        if ((e = launch_monitor<FLIP>(ka, L.dev, h->stream)) != hipSuccess) return e;
+        helper_busy = true;
+        if ((e = enqueue_bwd<M, FLIP, GENERIC>(ka, L, st, first_round, ka.B - first_round)) != hipSuccess) return e;
+        if (L.tail && (e = enqueue_tail(ka, *L.tail, st)) != hipSuccess) return e;
     } else {
         if ((e = enqueue_bwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         if (L.tail && (e = enqueue_tail(ka, *L.tail, st)) != hipSuccess) return e;
