@@ -47,7 +47,8 @@ static mxArray *dbl3(mwSize a, mwSize b, mwSize c)
 static void prescribe(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
     (void)nlhs;
-    if (nrhs != 19) mexErrMsgTxt("epiekf_pipeline_mex('prescribe', ...): 19 inputs expected");
+    // (an optional 20th input: epi_prescribe_desc.placement_tries -- the first sweep of a size keeps the fastest of that many device arenas)
+    if (nrhs != 19 && nrhs != 20) mexErrMsgTxt("epiekf_pipeline_mex('prescribe', ...): 19 inputs expected (+ optional placement_tries)");
     const mxArray *x = prhs[1], *u = prhs[2];
     if (mxGetNumberOfDimensions(u) != 3) mexErrMsgTxt("u must be R x n_npi x T");
     const mwSize *du = mxGetDimensions(u);
@@ -61,6 +62,7 @@ static void prescribe(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]
     memset(&d, 0, sizeof d);
     d.abi_version = EPIEKF_ABI_VERSION; d.R = (int32_t)R; d.P = (int32_t)P; d.T = (int32_t)T; d.t_hist = (int32_t)mxGetScalar(prhs[14]);
     d.n_npi = (int32_t)n; d.L = (int32_t)mxGetScalar(prhs[15]); d.order = (int32_t)mxGetScalar(prhs[16]); d.obs_type = (int32_t)mxGetScalar(prhs[17]);
+    if (nrhs == 20) d.placement_tries = (int32_t)mxGetScalar(prhs[19]);
     epi_prescribe_inputs in;
     memset(&in, 0, sizeof in);
     in.x = mxGetPr(x); in.u = mxGetPr(u); in.R_series = mxGetPr(prhs[3]); in.prm = mxGetPr(prhs[4]);
