@@ -42,6 +42,9 @@
 #ifndef EPI_LANE6_PS_LDS
 #define EPI_LANE6_PS_LDS 0
 #endif
+#ifndef EPI_LANE6_XD
+#define EPI_LANE6_XD 1           // X of the next step by LDS-DMA where every lane of the launch is alive (see eks_bwd_lane6)
+#endif
 #ifndef EPI_LANE6_X_LATE
 #define EPI_LANE6_X_LATE 0      // 1: X is requested after P(k+1|k) has been formed (behind the previous step's stores) instead of at the top
 #endif
@@ -128,6 +131,14 @@ EPI_DEV void lw_phase()
     asm volatile("; L6PHASE");
 #endif
 }
+// `buffer_load_dwordx4 ... lds` (gfx950: 16 bytes per lane): global memory straight into LDS at a wave-uniform LDS address + 16 x lane,
+// no register destination
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+// (the LDS destination is named by its 32-bit LDS address: a generic pointer cast back to LDS costs a null check per use)
+EPI_DEV void lw_dma16(rsrc_t r, unsigned lds_addr, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(uintptr_t)lds_addr, 16, voff, soff, 0, EPI_LD_STREAM_AUX);
+}
 // an LDS address the compiler cannot see through: what was written there is READ BACK, not kept in registers beside it
 // (hipcc forwards a store to a later load of the same LDS address -- and the value then stays live, which is what the
 // LDS copy is there to avoid)
@@ -185,14 +196,21 @@ EPI_DEV void lw_predict_cov_from_pa(const double (&A)[36], const double (&PA)[36
 // backward recursion (GenericExtendedKalmanFilter.m:204-230; X = pinv(P_MINUS) comes from eks_pinv)
 // ---------------------------------------------------------------------------
 // LATE_PF: the next step's small inputs are requested in the middle of the step instead of at its top
-template <int FLIP, int BLK, int RC, int LATE_PF = EPI_LANE6_LATE_PF>
+// XD = 1 (launches whose chain count is a multiple of BLK: every lane of every workgroup is alive): X of the NEXT step comes by
+// LDS-DMA (lw_dma16) while this step runs -- 21 packed rows of BLK x 8 bytes, two rows per instruction of the wave's BLK lanes -- into
+// an LDS image that the step reads when it forms J.  X is the one input that is requested long before its use (at the top, ahead of
+// the stores; used after P+ A' and P(k+1|k)): in registers it is parked in accumulation registers and fetched back, 168 of the
+// step's 373 such moves.
+template <int FLIP, int BLK, int RC, int LATE_PF = EPI_LANE6_LATE_PF, int XD = 0>
 __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int *__restrict__ dense_flag)
 {
+    __shared__ __attribute__((aligned(16))) double s_xd[XD ? 21 * BLK : 2];      // DMA image of X (a separate object: the compiler waits for a DMA only where this array is read)
     constexpr int M = 6, NS = 21;
     // one column per lane, BLK lanes: a, u_min, u_max, w (48 rows); the pending u_opt_smooth (12) and -- RC -- P(k|k) between its
     // use in P+ A' and in :223 (21): values that would otherwise sit in accumulation registers and cost four moves each
     __shared__ double vlds[(4 * kNpi + kNpi + (RC ? 21 + 6 : 0) + (EPI_LANE6_PS_LDS ? 21 : 0)) * BLK];
     if (*dense_flag) return;
+    const unsigned xd_base = (unsigned)(uintptr_t)(lds_ptr_t)s_xd;
     const int lane = threadIdx.x;
     const int c = a.c0 + blockIdx.x * BLK + lane;
     if (lane >= BLK || c >= a.c0 + a.cn) return;
@@ -283,6 +301,13 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
         for (int i = 0; i < M; i++) v[i] = lw_ld<BLK>(r, ll.v6, d.o6, i);
     };
 
+    // X of one step by DMA: this lane's 16-byte piece of two layout rows per instruction (the eleventh moves the last row alone)
+    const unsigned vxd = ((unsigned)c / BLK) * 21u * BLK * 8u + (unsigned)lane * 16u;
+    auto dma_x = [&](const LwDay &dd) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) lw_dma16(rX, xd_base + (unsigned)(2 * i * BLK * 8), vxd, dd.o21 + (unsigned)(2 * i * BLK * 8));
+        if (lane < BLK / 2) lw_dma16(rX, xd_base + (unsigned)(20 * BLK * 8), vxd, dd.o21 + (unsigned)(20 * BLK * 8));
+    };
     if (k_from < T - 2) {      // resume from the hand-over rows
 #pragma unroll
         for (int i = 0; i < M; i++) Ss[i] = a.hand_s[(size_t)i * hp + c];
@@ -349,7 +374,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
     auto step = [&](int k, const LwDay &d0, const LwDay &d1) __attribute__((always_inline)) {
         if (!LATE_PF && k > k_to) fetch_small(lw_next<FLIP ? 1 : -1>(d0, ds), d0, tpos<FLIP>(k - 1, T), nxt);
         if (!(EPI_LANE6_BIG_PF & 1)) ld_sym(rPp, d0, Pp);
-        if (!EPI_LANE6_X_LATE && !(EPI_LANE6_BIG_PF & 2)) {
+        if (!XD && !EPI_LANE6_X_LATE && !(EPI_LANE6_BIG_PF & 2)) {
 #pragma unroll
             for (int e = 0; e < NS; e++) X[e] = lw_ld<BLK>(rX, ll.v21, d1.o21, e);      // (garbage where the :211 guard fired, rk < 0: unused)
         }
@@ -416,9 +441,13 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
         lw_phase();
         // the next step's small inputs: requested only now (they return behind this step's X in any case, and are not needed
         // before the next step), so that they do not hold 37 registers through the phases above
-        if (EPI_LANE6_X_LATE && !(EPI_LANE6_BIG_PF & 2)) {
+        if (!XD && EPI_LANE6_X_LATE && !(EPI_LANE6_BIG_PF & 2)) {
 #pragma unroll
             for (int e = 0; e < NS; e++) X[e] = lw_ld<BLK>(rX, ll.v21, d1.o21, e);
+        }
+        if (XD) {              // the image the previous step (or the prologue) requested
+#pragma unroll
+            for (int e = 0; e < NS; e++) X[e] = s_xd[e * BLK + lane];
         }
         if (LATE_PF && k > k_to) fetch_small(lw_next<FLIP ? 1 : -1>(d0, ds), d0, tpos<FLIP>(k - 1, T), nxt);
         double J[M * M];
@@ -442,6 +471,10 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
             min_rank = rank < min_rank ? rank : min_rank;
         }
         lw_phase();
+        if (XD && k > k_to) {                                  // X has been consumed: the image takes the next step's (X of step k - 1 lies at the position of step k)
+            __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): the reads of the image are done before it is overwritten
+            dma_x(d0);
+        }
         if ((EPI_LANE6_BIG_PF & 2) && k > k_to) {             // X has been consumed: its registers take the next step's
 #pragma unroll
             for (int e = 0; e < NS; e++) X[e] = lw_ld<BLK>(rX, ll.v21, d0.o21, e);
@@ -528,6 +561,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
             if (k_from >= T - 2) terminal();
             ps_park();
             fetch_small(d0, d1, tpos<FLIP>(hi, T), cur);
+            if (XD) dma_x(d1);
             if (EPI_LANE6_BIG_PF & 1) ld_sym(rPp, d0, Pp);
             if (EPI_LANE6_BIG_PF & 2) {
 #pragma unroll
@@ -543,6 +577,7 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
         }
     }
     if (have_pend) flush();
+    if (XD) __builtin_amdgcn_s_waitcnt(0x0070);      // (no DMA is in flight when the wave ends: the last step requests none)
     ps_fetch();
     if (k_to > 0) {        // hand-over to the launch that continues with step k_to - 1
 #pragma unroll
@@ -571,12 +606,6 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
 // rank word (registers), P(k-1|k-1) (LDS)  |  J from the X image  |  request X of step k - 1 (LDS)  |  :218-226.
 // The loads are younger than the stores, so the one wait of a step is a plain vmcnt(0) -- about two thirds of a step after the
 // stores and half a step after the loads were issued.
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-// (the LDS destination is named by its 32-bit LDS address: a generic pointer cast back to LDS costs a null check per use)
-EPI_DEV void lw_dma16(rsrc_t r, unsigned lds_addr, unsigned voff, unsigned soff)
-{
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)(uintptr_t)lds_addr, 16, voff, soff, 0, EPI_LD_STREAM_AUX);
-}
 // packed row e = sidx(i, j) of a symmetric 6 x 6 array stored with all 36 rows: its row i + 6 j
 constexpr int lw_src_row(int e)
 {

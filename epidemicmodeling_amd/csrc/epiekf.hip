@@ -1393,7 +1393,8 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
 #if EPI_LANE6_BWD == 3
                 if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6d<FLIP, 40>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
 #else
-                if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 40, (EPI_LANE6_BWD > 1)>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                if (ka.blk == 40 && EPI_LANE6_XD && ka.cn % 40 == 0) hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 40, (EPI_LANE6_BWD > 1), EPI_LANE6_LATE_PF, 1>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 40, (EPI_LANE6_BWD > 1)>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
 #endif
                 else if (ka.blk == 48) hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 48, (EPI_LANE6_BWD > 1)>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                 else hipLaunchKernelGGL((eks_bwd_lane6<FLIP, 56, (EPI_LANE6_BWD > 1)>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
