@@ -654,10 +654,23 @@ struct HexBwdIn { double Sp[6], Sm1[6], u[2], Ppc[6], Pm1c[6], X[21]; int rk; };
 // PF = 1: a step's inputs are requested one step ahead into one of two register sets (256 + 22 registers: one wave per SIMD) --
 // for launches of at most one wave per SIMD; PF = 0: requested at the start of the step (242 registers, no accumulation
 // registers: TWO waves per SIMD, which hide each other's memory latency) -- for larger launches.
+// PF = 2 (round 6, BLK = 10 only): one step ahead as with PF = 1, but by LDS-DMA (`buffer_load_dwordx4 ... lds`).  With ten chains
+// per layout block a day of a wave's S_PLUS / S_MINUS / P_PLUS / X is ONE contiguous run of 480 / 480 / 2 880 / 1 680 bytes, which
+// seven instructions of 64 x 16 bytes copy into an LDS image; the lanes then pick their entries out of the image with ds_read_b64.
+// The twelve 8-byte loads per lane and step of PF = 1 touch the same bytes in 60 x 12 scattered pieces: it was the CU's address
+// unit that those kept busy (round 5: "0.77 ms without its loads" of 1.13), not the memory.
+constexpr int kHxImgSp = 0, kHxImgSm = 60, kHxImgP = 120, kHxImgX = 480, kHxImg = 692;      // doubles; 5 536 bytes per image
+typedef __attribute__((address_space(3))) void *hx_lds_ptr_t;
+EPI_DEV void hx_dma16(rsrc_t r, unsigned lds_addr, unsigned voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (hx_lds_ptr_t)(uintptr_t)lds_addr, 16, voff, soff, 0, EPI_LD_STREAM_AUX);
+}
 template <int FLIP, int BLK, int PF = 1>
 __global__ __launch_bounds__(kWave, PF ? 1 : 2) void eks_bwd_hex(const KArgs a, const int *__restrict__ dense_flag)
 {
     constexpr int M = 6;
+    static_assert(PF != 2 || BLK == kHG, "the DMA images assume one layout block per wavefront");
+    __shared__ __attribute__((aligned(16))) double imgA[PF == 2 ? kHxImg : 2], imgB[PF == 2 ? kHxImg : 2];
     __shared__ __attribute__((aligned(16))) double tJ[kHGp * kHT], tB[kHGp * kHT], tC[kHGp * kHT];
     __shared__ __attribute__((aligned(16))) double vS[kHGp * kHV], vTm[kHGp * kHN];
 
@@ -786,6 +799,39 @@ __global__ __launch_bounds__(kWave, PF ? 1 : 2) void eks_bwd_hex(const KArgs a, 
 #endif
 #endif
     };
+    // PF = 2: the same inputs by DMA into an image, the two small ones (controls, rank word) into registers
+    struct HexSmall { double u[2]; int rk; };
+    const unsigned lane16 = (unsigned)threadIdx.x * 16u;
+    // (the WAVE's layout block, not the lane's: idle lanes mirror the batch's last chain, which lies in another block)
+    const unsigned wblk = (unsigned)a.c0 / (unsigned)kHG + blockIdx.x;
+    const unsigned vo6 = wblk * (6u * 80u) + lane16, vo36 = wblk * (36u * 80u) + lane16, vo21 = wblk * (21u * 80u) + lane16;
+    auto fetch_dma = [&](const HexDay &dt, const HexDay &dt1, unsigned img, HexSmall &sm) __attribute__((always_inline)) {
+        const rsrc_t rSp = hx_rsrc(w.S_PLUS), rSm = hx_rsrc(w.S_MINUS), rP = hx_rsrc(w.P_PLUS), rX = hx_rsrc(w.X);
+        const unsigned lane = threadIdx.x;
+        if (lane < 30u) hx_dma16(rSp, img + kHxImgSp * 8u, vo6, dt.o6);
+        if (lane < 30u) hx_dma16(rSm, img + kHxImgSm * 8u, vo6, dt1.o6);
+        hx_dma16(rP, img + kHxImgP * 8u, vo36, dt.o36);
+        hx_dma16(rP, img + kHxImgP * 8u + 1024u, vo36, dt.o36 + 1024u);
+        if (lane < 52u) hx_dma16(rP, img + kHxImgP * 8u + 2048u, vo36, dt.o36 + 2048u);
+        hx_dma16(rX, img + kHxImgX * 8u, vo21, dt1.o21);
+        if (lane < 41u) hx_dma16(rX, img + kHxImgX * 8u + 1024u, vo21, dt1.o21 + 1024u);
+        hx_load_u_at(w.u, a, dt.ou, su, j, sm.u);
+        sm.rk = hx_load_word(w.rankbuf, HexAt{dt1.o1 >> 1}, lay);
+    };
+    // my entries out of an image: element (row r, chain g) of a run lies at r * 10 + g
+    auto unpack = [&](const double *img, const HexSmall &sm, HexBwdIn &d) __attribute__((always_inline)) {
+#if EPI_HEX_SHARE_LOADS
+        const int g = h.g;
+        d.Spj = img[kHxImgSp + j * 10 + g];
+        d.Sm1j = img[kHxImgSm + j * 10 + g];
+#pragma unroll
+        for (int i = 0; i < 6; i++) d.Ppc[i] = img[kHxImgP + (j + 6 * i) * 10 + g];
+#pragma unroll
+        for (int m = 0; m < 3; m++) d.Xp[m] = img[kHxImgX + (j + 6 * m) * 10 + g];
+        d.Xp[3] = img[kHxImgX + (18 + (j < 3 ? j : 2)) * 10 + g];
+        d.u[0] = sm.u[0]; d.u[1] = sm.u[1]; d.rk = sm.rk;
+#endif
+    };
     auto step = [&](const HexDay &dt, const HexBwdIn &cur) __attribute__((always_inline)) {
 #if EPI_HEX_SHARE_LOADS
         double Sp[M], Sm1[M], X[24];
@@ -910,6 +956,7 @@ __global__ __launch_bounds__(kWave, PF ? 1 : 2) void eks_bwd_hex(const KArgs a, 
     const HexDayStride ds = hx_day_stride(a, lay);
     const int W = hx_window(a, lay);
     HexBwdIn bufA, bufB;
+    HexSmall smA, smB;
     int k = k_from;
     bool first = true;
     if (k_from >= T - 2 && k_from < k_to) {      // T == 1: no step, the terminal condition alone
@@ -927,6 +974,31 @@ __global__ __launch_bounds__(kWave, PF ? 1 : 2) void eks_bwd_hex(const KArgs a, 
                 step(d0, bufA);
                 d1 = d0;
                 d0 = hx_day_next<DIR>(d0, ds);
+            }
+        } else if constexpr (PF == 2) {
+            // two images used alternately (the loop body exists twice, each naming its image: the compiler waits for the DMA into the
+            // image a step reads and for no other); a window that is not the last has an even number of steps and hands image A on
+            const unsigned aA = (unsigned)(uintptr_t)(hx_lds_ptr_t)imgA, aB = (unsigned)(uintptr_t)(hx_lds_ptr_t)imgB;
+            if (first) {
+                fetch_dma(d0, d1, aA, smA);
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            // The image a step reads was requested a step ago; the wait is explicit -- all but the ten vector-memory operations of the
+            // group just issued (seven DMA, the two control loads, the rank word) have completed, or all when nothing was issued --
+            // because nothing tells the compiler that the DMA (its LDS address is an integer) wrote THIS array: without it a step
+            // read a stale image once in a while, when the pinv grids beside the smoother made memory slow (found by the shard test).
+            while (k >= lo) {
+                const HexDay dm1 = hx_day_next<DIR>(d0, ds);
+                if (k > k_to) { fetch_dma(dm1, d0, aB, smB); __builtin_amdgcn_s_waitcnt(0x0F7A); } else __builtin_amdgcn_s_waitcnt(0x0F70);
+                unpack(imgA, smA, bufA);
+                step(d0, bufA);
+                if (--k < lo) break;
+                const HexDay dm2 = hx_day_next<DIR>(dm1, ds);
+                if (k > k_to) { fetch_dma(dm2, dm1, aA, smA); __builtin_amdgcn_s_waitcnt(0x0F7A); } else __builtin_amdgcn_s_waitcnt(0x0F70);
+                unpack(imgB, smB, bufB);
+                step(dm1, bufB);
+                --k;
+                d0 = dm2;
             }
         } else {
             // two input sets used alternately (the loop body exists twice): the prefetched values are consumed where they landed; a
@@ -949,6 +1021,7 @@ __global__ __launch_bounds__(kWave, PF ? 1 : 2) void eks_bwd_hex(const KArgs a, 
         }
         first = false;
     }
+    if (PF == 2) __builtin_amdgcn_s_waitcnt(0x0070);      // (no DMA is in flight when the wave ends: the last step requests none)
     if (!h.live) return;
     if (k_to > 0) {        // hand-over to the launch that continues with step k_to - 1
         a.hand_s[(size_t)j * hp + c] = hx_pick(Ss, j);

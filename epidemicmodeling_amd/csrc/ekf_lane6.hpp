@@ -445,7 +445,9 @@ __global__ __launch_bounds__(kWave) void eks_bwd_lane6(const KArgs a, const int 
 #pragma unroll
             for (int e = 0; e < NS; e++) X[e] = lw_ld<BLK>(rX, ll.v21, d1.o21, e);
         }
-        if (XD) {              // the image the previous step (or the prologue) requested
+        if (XD) {              // the image the previous step (or the prologue) requested.  It HAS landed: at least 99 vector-memory operations (this
+            // step's 21 loads of P(k|k), the 78 stores of the previous step's results) were issued behind its DMA, a wave has at most 64 in
+            // flight and they complete in order -- and the step loop ends with a full wait for the small inputs requested before it
 #pragma unroll
             for (int e = 0; e < NS; e++) X[e] = s_xd[e * BLK + lane];
         }

@@ -1363,7 +1363,11 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
                 const unsigned hblocks = (unsigned)((ka.B + kHG - 1) / kHG);
                 const bool pf = (long)hblocks <= (long)simd_count(L.dev);      // one wave per SIMD: prefetch; beyond: two waves per SIMD
                 if (ka.blk == kHG) {
-                    if (pf) hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+#ifndef EPI_HEX_BWD_DMA
+#define EPI_HEX_BWD_DMA 1
+#endif
+                    if (pf && EPI_HEX_BWD_DMA) hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG, 2>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
+                    else if (pf) hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                     else hipLaunchKernelGGL((eks_bwd_hex<FLIP, kHG, 0>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                 } else {
                     if (pf) hipLaunchKernelGGL((eks_bwd_hex<FLIP, 0, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
