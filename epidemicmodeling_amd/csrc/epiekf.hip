@@ -1197,11 +1197,12 @@ static hipError_t launch_monitor(const KArgs &ka, int dev, hipStream_t st)
 #endif
 // forward kernel(s) over filter steps [ka.k_begin, ka.k_end) of all chains
 template <int M, int FLIP, int GENERIC>
-static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
+static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st, int c0 = 0, int cn = -1)
 {
     ka.c0 = 0; ka.cn = ka.B;
     ka.lw = balanced_lanes(ka.B, M == 6 ? 1 : 2, L.dev);
-    const int blocks = (ka.B + ka.lw - 1) / ka.lw;
+    if (cn >= 0) { ka.c0 = c0; ka.cn = cn; }      // a chain range (a multiple of the wave's lanes; the one-lane kernels only)
+    const int blocks = (ka.cn + ka.lw - 1) / ka.lw;
     const size_t shmem = (size_t)3 * ka.L * kWave * sizeof(double);
     // hint 0: both variants are enqueued, the one ekf_precheck did not select returns at once
     const bool run_sym = GENERIC && L.hint != 2, run_dense = !GENERIC || L.hint != 1;
@@ -1315,12 +1316,13 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st)
 
 // X = pinv(P(j|j-1)) for the `nsteps` array positions from pinv_pos0 + step0 on, all chains
 template <int M>
-static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st)
+static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st, int c0 = 0, int cn = -1)
 {
     if (nsteps <= 0) return hipSuccess;
     ka.c0 = 0; ka.cn = ka.B; ka.pinv_step0 = step0;
+    if (cn >= 0) { ka.c0 = c0; ka.cn = cn; }
     // x extent rounded up to a multiple of 8: the kernel re-orders its tiles so that every XCD gets a contiguous eighth per step
-    unsigned tiles = (unsigned)((ka.B + pinv_wg<M>() - 1) / pinv_wg<M>());
+    unsigned tiles = (unsigned)((ka.cn + pinv_wg<M>() - 1) / pinv_wg<M>());
     if (ka.only && tiles > 8u) tiles = 8u;      // the second pass of exact_nonfinite walks the list of marked chains (see eks_pinv)
     if (ka.only) hipLaunchKernelGGL((eks_pinv<M, 1>), dim3(tiles >= 8u ? ((tiles + 7u) & ~7u) : tiles, (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
     else hipLaunchKernelGGL((eks_pinv<M, 0>), dim3(tiles >= 8u ? ((tiles + 7u) & ~7u) : tiles, (unsigned)nsteps), dim3(pinv_wg<M>()), 0, st, ka);
@@ -1553,6 +1555,7 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
     };
     const long fwd_waves = ka.hex ? ((long)ka.B + kHG - 1) / kHG : ka.quad ? ((long)ka.B + kQC - 1) / kQC : ((long)ka.B + kWave - 1) / kWave;
     // (one wavefront per chain: the pinv grid of so few chains takes ~30 us, nothing to pipeline -- unless asked for)
+    const bool force_split = (L.test_flags >> 2) & 1;                                                      // test hook
     const bool force_rp = (L.test_flags & 1) && ka.hex && ka.mon_hoist && T >= 4 && L.time_pipe >= 0;      // test hook
     const bool tp = !force_rp && ka.mon_hoist && !ka.stor && T >= 128 && L.time_pipe >= 0 &&
                     (L.time_pipe == 1 || (!ka.wave && fwd_waves * 4 <= (long)simd_count(L.dev) * 3));
@@ -1635,9 +1638,31 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         if ((e = fork(h->stream, st)) != hipSuccess) return e;       // the smoother needs every pinv grid
         helper_busy = true;
     } else {
+        // A one-lane batch that runs in ROUNDS of resident waves (more waves than SIMDs: the headline sweep): the chains of the forward
+        // kernel's first round and the rest are two launches, and the pinv grid of the first range runs on the helper stream beside
+        // the forward kernel of the second (whose 851 waves leave SIMDs and registers free at 75 000 chains; the forward kernel is
+        // bound by its stores, the grid by the vector unit): 0.15 ms of the grid's 3.0 hidden (profiles/r06/ab_pinv_beside_fwd.txt).
+        // epi_batch_desc.test_flags bit 2 cuts ANY one-lane batch of two waves or more in the middle the same way (test hook).
+#ifndef EPI_PINV_BESIDE_FWD
+#define EPI_PINV_BESIDE_FWD 1
+#endif
+        const int lwf = balanced_lanes(ka.B, M == 6 ? 1 : 2, L.dev);
+        const long wavesf = ((long)ka.B + lwf - 1) / lwf;
+        const int cA = force_split ? (int)(wavesf / 2) * lwf : simd_count(L.dev) * lwf;
+        if (EPI_PINV_BESIDE_FWD && M == 6 && GENERIC && !ka.hex && !ka.quad && !ka.wave && !ka.only && L.hint != 2 && cA > 0 && cA < ka.B &&
+            (force_split || lwf < kWave)) {
+            if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st, 0, cA)) != hipSuccess) return e;
+            if ((e = fork(st, h->stream)) != hipSuccess) return e;
+            if ((e = enqueue_pinv<M>(ka, 0, T - 1, h->stream, 0, cA)) != hipSuccess) return e;
+            if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st, cA, ka.B - cA)) != hipSuccess) return e;
+            if ((e = fork(h->stream, st)) != hipSuccess) return e;
+            if (ka.mon_hoist && (ka.rho || ka.f.rho) && (e = fork(st, h->stream)) != hipSuccess) return e;
+            if ((e = enqueue_pinv<M>(ka, 0, T - 1, st, cA, ka.B - cA)) != hipSuccess) return e;
+        } else {
         if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         if (ka.mon_hoist && (ka.rho || ka.f.rho) && (e = fork(st, h->stream)) != hipSuccess) return e;
         if ((e = enqueue_pinv<M>(ka, 0, T - 1, st)) != hipSuccess) return e;
+        }
     }
     // A one-lane batch that runs in ROUNDS (more 64-chain waves than SIMDs: the headline sweep) on the fixed-descriptor smoother:
     // the chains of the smoother's first round of resident waves and the rest are two launches, and the monitor starts between
@@ -1650,8 +1675,9 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
 #ifndef EPI_MONITOR_LATE
 #define EPI_MONITOR_LATE 1
 #endif
-        first_round = simd_count(L.dev) * ka.blk;
-        mon_late = EPI_MONITOR_LATE && !tp && in_rounds && EPI_LANE6_BWD && !ka.stor && lane6_block(ka.blk) && (long)ka.blk * ka.nblk <= (1L << 20) &&
+        const bool cut = force_split && !ka.hex && !ka.quad && !ka.wave && ka.nblk >= 2;        // test hook: the two launches at any size
+        first_round = cut ? (ka.nblk / 2) * ka.blk : simd_count(L.dev) * ka.blk;
+        mon_late = EPI_MONITOR_LATE && !tp && (in_rounds || cut) && EPI_LANE6_BWD && !ka.stor && lane6_block(ka.blk) && (long)ka.blk * ka.nblk <= (1L << 20) &&
                    ka.mon_hoist && (ka.rho || ka.f.rho) && first_round < ka.B;
     }
     if (!mon_late && ka.mon_hoist && (ka.rho || ka.f.rho)) {
@@ -1661,7 +1687,7 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
     // (Not for a one-lane batch that runs in ROUNDS of resident waves -- more 64-chain waves than SIMDs, the headline sweep: every
     // SIMD is taken by a 512-register wave, the tail finds no room beside the smoother and a second launch costs the smoother a
     // second pair of rounds: 15.1-15.9 against 15.6-16.2 ms per pass over four alternating runs, profiles/r06/ab_monitor_par.txt.)
-    if (!in_rounds && L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2 && !ka.wave) {
+    if (!in_rounds && !mon_late && L.tail && L.tail->t_hist >= 1 && L.tail->t_hist <= T - 2 && !ka.wave) {
         KArgs kb = ka;
         kb.bk_from = T - 2; kb.bk_to = L.tail->t_hist;              // the horizon days
         if ((e = enqueue_bwd<M, FLIP, GENERIC>(kb, L, st)) != hipSuccess) return e;
@@ -1747,7 +1773,7 @@ int epi_ekf_validate(const epi_batch_desc *d, char *err)
     if (d->exact_nonfinite < -1 || d->exact_nonfinite > 1) { set_err(err, "exact_nonfinite must be 0 (default: on), 1 (on) or -1 (off)"); return EPI_ERR_BAD_ARG; }
     if (d->placement_tries < 0 || d->placement_tries > EPI_PLACEMENT_MAX_TRIES) { set_err(err, "placement_tries must be 0 .. EPI_PLACEMENT_MAX_TRIES"); return EPI_ERR_BAD_ARG; }
     if (d->test_window < 0 || d->test_window == 1) { set_err(err, "test_window must be 0 (production) or >= 2"); return EPI_ERR_BAD_ARG; }
-    if (d->test_flags < 0 || d->test_flags > 3) { set_err(err, "test_flags must be 0 (production) .. 3"); return EPI_ERR_BAD_ARG; }
+    if (d->test_flags < 0 || d->test_flags > 7) { set_err(err, "test_flags must be 0 (production) .. 7"); return EPI_ERR_BAD_ARG; }
     if (padded_chains(d) > ((size_t)1 << 23)) { set_err(err, "B rounded up to lane_block exceeds 2^23"); return EPI_ERR_BAD_ARG; }
     if ((size_t)3 * d->L * kWave * sizeof(double) > 160u * 1024u) { set_err(err, "inv_monitor_len too large for LDS (max 106)"); return EPI_ERR_UNSUPPORTED; }
     return EPI_OK;

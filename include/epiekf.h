@@ -198,7 +198,11 @@ typedef struct epi_batch_desc {
                              beside the smoother's first launches) whatever the batch size and day count, which otherwise
                              engages beyond 768 hex wavefronts and 128 days only.
                              bit 1: the innovation monitor's scan kernel (ekf_monitor) replays rho whatever the batch size; below
-                             65 537 chains the scan-free grid (ekf_monitor_par) otherwise does. */
+                             65 537 chains the scan-free grid (ekf_monitor_par) otherwise does.
+                             bit 2: a one-lane batch is cut into two chain ranges in the middle of its waves -- forward kernel,
+                             pinv grid (the first range's beside the second forward launch) and, on the fixed-descriptor
+                             smoother, the smoother with the monitor between its launches -- as batches of more waves than SIMDs
+                             are cut after their first round of resident waves. */
 } epi_batch_desc;
 
 typedef enum epi_shape { EPI_SHAPE_AUTO = 0, EPI_SHAPE_LANE = 1, EPI_SHAPE_QUAD = 2, EPI_SHAPE_WAVE = 3, EPI_SHAPE_HEX = 4 } epi_shape;

@@ -83,7 +83,7 @@ def build(draw):
     shape = draw(st.sampled_from(["lane", "quad", "wave", "hex", "hex", "auto"]))
     # test hooks of the descriptor: short addressing windows (hex and fixed-descriptor lane kernels), the reverse-time pipeline
     # at a batch size that would not choose it
-    hooks = dict(test_window=draw(st.sampled_from([0, 0, 2, 3, 6])), test_flags=draw(st.sampled_from([0, 0, 1])))
+    hooks = dict(test_window=draw(st.sampled_from([0, 0, 2, 3, 6])), test_flags=draw(st.sampled_from([0, 0, 1, 4, 5, 6])))
     return w, lane_block, time_pipe, kind, shape, hooks
 
 
@@ -132,7 +132,7 @@ def test_random_sweeps_through_the_one_call_entry(gpu_device, data):
     lane_block = draw(st.sampled_from([0, 0, 8, 16, 40, "auto"]))
     shape = draw(st.sampled_from(["lane", "quad", "wave", "hex", "auto"]))
     time_pipe = draw(st.sampled_from([0, 1, -1]))
-    hooks = dict(test_window=draw(st.sampled_from([0, 0, 2, 5])), test_flags=draw(st.sampled_from([0, 1])))
+    hooks = dict(test_window=draw(st.sampled_from([0, 0, 2, 5])), test_flags=draw(st.sampled_from([0, 1, 4, 5])))
     with_front = draw(st.booleans())
     n, B = w.n_npi, w.B
     sp = np.zeros((batch.SIM_PRM_COUNT, B))
