@@ -1655,9 +1655,9 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
             if ((e = fork(st, h->stream)) != hipSuccess) return e;
             if ((e = enqueue_pinv<M>(ka, 0, T - 1, h->stream, 0, cA)) != hipSuccess) return e;
             if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st, cA, ka.B - cA)) != hipSuccess) return e;
-            if ((e = fork(h->stream, st)) != hipSuccess) return e;
             if (ka.mon_hoist && (ka.rho || ka.f.rho) && (e = fork(st, h->stream)) != hipSuccess) return e;
-            if ((e = enqueue_pinv<M>(ka, 0, T - 1, st, cA, ka.B - cA)) != hipSuccess) return e;
+            if ((e = enqueue_pinv<M>(ka, 0, T - 1, st, cA, ka.B - cA)) != hipSuccess) return e;     // beside the tail of the first range's grid
+            if ((e = fork(h->stream, st)) != hipSuccess) return e;
         } else {
         if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         if (ka.mon_hoist && (ka.rho || ka.f.rho) && (e = fork(st, h->stream)) != hipSuccess) return e;
@@ -1676,6 +1676,8 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
 #define EPI_MONITOR_LATE 1
 #endif
         const bool cut = force_split && !ka.hex && !ka.quad && !ka.wave && ka.nblk >= 2;        // test hook: the two launches at any size
+        // (a first launch of 1 004 / 984 / 964 / 944 waves instead of the 1 024 that are resident at once: level, 14.41-14.88 ms per pass
+        // whatever the cut; the monitor ahead of the first launch instead of between the two: +0.15 ms -- profiles/r06/ab_bwd_balance*.txt)
         first_round = cut ? (ka.nblk / 2) * ka.blk : simd_count(L.dev) * ka.blk;
         mon_late = EPI_MONITOR_LATE && !tp && (in_rounds || cut) && EPI_LANE6_BWD && !ka.stor && lane6_block(ka.blk) && (long)ka.blk * ka.nblk <= (1L << 20) &&
                    ka.mon_hoist && (ka.rho || ka.f.rho) && first_round < ka.B;
