@@ -1210,8 +1210,8 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
     if constexpr (M == 6 && !GENERIC) {
         if (ka.wave && !ka.only) {  // NewCaseEKFEstimatorWithOptimalNPI, one wavefront per chain (monitor always inline)
             const size_t wshm = (size_t)6 * ka.L * sizeof(double);
-            if (ka.L == 21) hipLaunchKernelGGL((ekf_fwd_wave<0, 1, 21, 0>), dim3((unsigned)ka.B), dim3(kWave), wshm, st, ka, (const int *)nullptr);
-            else hipLaunchKernelGGL((ekf_fwd_wave<0, 1, 0, 0>), dim3((unsigned)ka.B), dim3(kWave), wshm, st, ka, (const int *)nullptr);
+            if (ka.L == 21) hipLaunchKernelGGL((ekf_fwd_wave<0, 1, 21, 0>), dim3((unsigned)ka.cn), dim3(kWave), wshm, st, ka, (const int *)nullptr);
+            else hipLaunchKernelGGL((ekf_fwd_wave<0, 1, 0, 0>), dim3((unsigned)ka.cn), dim3(kWave), wshm, st, ka, (const int *)nullptr);
             return hipGetLastError();
         }
     }
@@ -1219,23 +1219,23 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
         bool done = false;
         if constexpr (M == 6 && GENERIC) {
             if (ka.wave) {          // one wavefront per chain (ekf_wave.hpp); with a scalar R_v the monitor runs inline
-                if (ka.mon_hoist) hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 0>), dim3((unsigned)ka.B), dim3(kWave), 0, st, ka, ka.dense_flag);
-                else if (ka.L == 21) hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 1, 21>), dim3((unsigned)ka.B), dim3(kWave), (size_t)6 * ka.L * sizeof(double), st, ka, ka.dense_flag);
-                else hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 1, 0>), dim3((unsigned)ka.B), dim3(kWave), (size_t)6 * ka.L * sizeof(double), st, ka, ka.dense_flag);
+                if (ka.mon_hoist) hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 0>), dim3((unsigned)ka.cn), dim3(kWave), 0, st, ka, ka.dense_flag);
+                else if (ka.L == 21) hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 1, 21>), dim3((unsigned)ka.cn), dim3(kWave), (size_t)6 * ka.L * sizeof(double), st, ka, ka.dense_flag);
+                else hipLaunchKernelGGL((ekf_fwd_wave<FLIP, 1, 0>), dim3((unsigned)ka.cn), dim3(kWave), (size_t)6 * ka.L * sizeof(double), st, ka, ka.dense_flag);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 done = true;
             }
         }
         if constexpr (M == 3 && GENERIC) {
             if (ka.wave) {          // seven chains per wavefront, nine lanes each
-                hipLaunchKernelGGL((ekf_fwd_wave3<FLIP>), dim3((unsigned)((ka.B + kW3G - 1) / kW3G)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                hipLaunchKernelGGL((ekf_fwd_wave3<FLIP>), dim3((unsigned)((ka.cn + kW3G - 1) / kW3G)), dim3(kWave), 0, st, ka, ka.dense_flag);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 done = true;
             }
         }
         if constexpr (M == 6 && GENERIC) {
             if (ka.hex && !done) {  // six lanes per chain, ten chains per wavefront (ekf_hex.hpp)
-                const unsigned hblocks = (unsigned)((ka.B + kHG - 1) / kHG);
+                const unsigned hblocks = (unsigned)((ka.cn + kHG - 1) / kHG);
                 const bool solo = (long)hblocks <= (long)simd_count(L.dev);   // every wave can have a SIMD of its own: keep it that way
                 if (ka.blk == kHG) {
                     if (solo) hipLaunchKernelGGL((ekf_fwd_hex<FLIP, kHG, 1>), dim3(hblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
@@ -1252,7 +1252,7 @@ static hipError_t enqueue_fwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
             if (ka.quad && !done) {
                 // four lanes per chain, 16 chains per wavefront (ekf_quad.hpp): the specialisation for the layout and the
                 // window length this shape is meant for, or the general one
-                const int qblocks = (ka.B + kQC - 1) / kQC;
+                const int qblocks = (ka.cn + kQC - 1) / kQC;
                 const size_t qshm = ((size_t)(ka.mon_hoist ? 0 : 6 * ka.L) + kNpi) * kQC * sizeof(double);
                 const bool fast = ka.blk == kQC && ka.L == 21;
                 const bool solo = qblocks <= simd_count(L.dev);   // every wave can have a SIMD of its own: keep it that way
@@ -1330,19 +1330,20 @@ static hipError_t enqueue_pinv(KArgs ka, int step0, int nsteps, hipStream_t st, 
 }
 
 // backward recursion over smoother steps ka.bk_from ... ka.bk_to (the dense kernels only know the full range)
-// (c0, cn: a chain range -- a multiple of the layout block -- for the fixed-descriptor one-lane smoother; every other kernel
-// takes the whole batch)
+// (c0, cn: a chain range -- a multiple of the chains one wave of the shape holds: the layout block of the fixed-descriptor one-lane
+// smoother, ten chains in the hex shape)
 template <int M, int FLIP, int GENERIC>
 static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st, int c0 = 0, int cn = -1)
 {
     ka.c0 = 0; ka.cn = ka.B;
     ka.lw = balanced_lanes(ka.B, M == 6 ? 1 : 2, L.dev);
-    const int blocks = (ka.B + ka.lw - 1) / ka.lw;
+    if (cn >= 0) { ka.c0 = c0; ka.cn = cn; }      // a chain range: a multiple of the chains a wave of the shape holds
+    const int blocks = (ka.cn + ka.lw - 1) / ka.lw;
     const bool run_sym = GENERIC && L.hint != 2, run_dense = !GENERIC || L.hint != 1;
     hipError_t e = hipSuccess;
     if constexpr (M == 6 && !GENERIC) {
         if (ka.wave && !ka.only) {
-            hipLaunchKernelGGL(eks_bwd_wave_nc, dim3((unsigned)ka.B), dim3(kWave), 0, st, ka);
+            hipLaunchKernelGGL(eks_bwd_wave_nc, dim3((unsigned)ka.cn), dim3(kWave), 0, st, ka);
             return hipGetLastError();
         }
     }
@@ -1350,19 +1351,19 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
         bool done = false;
         if constexpr (M == 6 && GENERIC) {
             if (ka.wave) {
-                hipLaunchKernelGGL((eks_bwd_wave<FLIP>), dim3((unsigned)ka.B), dim3(kWave), 0, st, ka, ka.dense_flag);
+                hipLaunchKernelGGL((eks_bwd_wave<FLIP>), dim3((unsigned)ka.cn), dim3(kWave), 0, st, ka, ka.dense_flag);
                 done = true;
             }
         }
         if constexpr (M == 3 && GENERIC) {
             if (ka.wave) {
-                hipLaunchKernelGGL((eks_bwd_wave3<FLIP>), dim3((unsigned)((ka.B + kW3G - 1) / kW3G)), dim3(kWave), 0, st, ka, ka.dense_flag);
+                hipLaunchKernelGGL((eks_bwd_wave3<FLIP>), dim3((unsigned)((ka.cn + kW3G - 1) / kW3G)), dim3(kWave), 0, st, ka, ka.dense_flag);
                 done = true;
             }
         }
         if constexpr (M == 6 && GENERIC) {
             if (ka.hex && !done) {
-                const unsigned hblocks = (unsigned)((ka.B + kHG - 1) / kHG);
+                const unsigned hblocks = (unsigned)((ka.cn + kHG - 1) / kHG);
                 const bool pf = (long)hblocks <= (long)simd_count(L.dev);      // one wave per SIMD: prefetch; beyond: two waves per SIMD
                 if (ka.blk == kHG) {
 #ifndef EPI_HEX_BWD_DMA
@@ -1380,7 +1381,7 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
         }
         if constexpr (M == 6 && GENERIC) {
             if (ka.quad && !done) {
-                const int qblocks = (ka.B + kQC - 1) / kQC;
+                const int qblocks = (ka.cn + kQC - 1) / kQC;
                 if (ka.blk == kQC) hipLaunchKernelGGL((eks_bwd_quad<FLIP, kQC>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                 else hipLaunchKernelGGL((eks_bwd_quad<FLIP, 0>), dim3(qblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
                 done = true;
@@ -1394,7 +1395,6 @@ static hipError_t enqueue_bwd(KArgs ka, const Launch &L, hipStream_t st, int c0 
             // such a batch is not issue-bound, profiles/r06/ab_n2_shard.txt)
             const bool l6_ok = lane6_block(ka.blk);
             if (!done && EPI_LANE6_BWD && !ka.stor && l6_ok && (long)ka.blk * ka.nblk <= (1L << 20)) {
-                if (cn >= 0) { ka.c0 = c0; ka.cn = cn; }
                 const int lblocks = (ka.cn + ka.blk - 1) / ka.blk;
 #if EPI_LANE6_BWD == 3
                 if (ka.blk == 40) hipLaunchKernelGGL((eks_bwd_lane6d<FLIP, 40>), dim3(lblocks), dim3(kWave), 0, st, ka, ka.dense_flag);
@@ -1569,6 +1569,11 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
 #define EPI_REVERSE_PIPE 1
 #endif
     const bool rp = force_rp || (EPI_REVERSE_PIPE && !tp && ka.hex && ka.mon_hoist && T >= 128 && L.time_pipe >= 0);
+    // (Round 6, measured and not adopted: the hex shape beyond one wavefront per SIMD -- 10 241 .. 20 480 chains, the shard of the headline
+    // sweep on one of 4 GPUs -- as TWO chain ranges through the one-wave-per-SIMD kernels, pipelined across the ranges (the pinv grid of
+    // the first beside the forward kernel of the second, the grid of the second beside the smoother of the first) instead of the
+    // two-waves-per-SIMD kernels pipelined in reverse time: 5.20-5.28 against 4.58-4.80 ms at 18 750 chains, 3.75-3.80 against 3.06-3.09 at
+    // 10 375 -- profiles/r06/ab_hex_rounds.txt.)
     if (rp) {
         if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st)) != hipSuccess) return e;
         if ((e = fork(st, h->stream)) != hipSuccess) return e;
