@@ -1654,8 +1654,10 @@ static hipError_t launch_chain(const KArgs &ka, const Launch &L, hipStream_t st)
         const int lwf = balanced_lanes(ka.B, M == 6 ? 1 : 2, L.dev);
         const long wavesf = ((long)ka.B + lwf - 1) / lwf;
         const int cA = force_split ? (int)(wavesf / 2) * lwf : simd_count(L.dev) * lwf;
+        // (not when neither P(k|k-1) nor P(k|k) is an output: that forward kernel fits TWO waves per SIMD and the headline's 1 875 are
+        // resident at once -- cut in two launches it took 1.1 ms longer, bench_cfg4_reduced 13.6 -> 14.7 ms)
         if (EPI_PINV_BESIDE_FWD && M == 6 && GENERIC && !ka.hex && !ka.quad && !ka.wave && !ka.only && L.hint != 2 && cA > 0 && cA < ka.B &&
-            (force_split || lwf < kWave)) {
+            (force_split || (lwf < kWave && ka.ws_upper != 3))) {
             if ((e = enqueue_fwd<M, FLIP, GENERIC>(ka, L, st, 0, cA)) != hipSuccess) return e;
             if ((e = fork(st, h->stream)) != hipSuccess) return e;
             if ((e = enqueue_pinv<M>(ka, 0, T - 1, h->stream, 0, cA)) != hipSuccess) return e;
