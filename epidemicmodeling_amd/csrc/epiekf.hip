@@ -2091,8 +2091,10 @@ static HostCtx *ctx_acquire(int device, hipError_t *e)
     if (device < 0 || device >= kMaxDevices) { *e = hipErrorInvalidDevice; return nullptr; }
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
+        size_t pick = g_pool.size();               // the idle context of this device with the largest arena
         for (size_t i = 0; i < g_pool.size(); i++)
-            if (g_pool[i]->device == device) { HostCtx *c = g_pool[i]; g_pool.erase(g_pool.begin() + (long)i); *e = hipSetDevice(device); return c; }
+            if (g_pool[i]->device == device && (pick == g_pool.size() || g_pool[i]->arena_bytes > g_pool[pick]->arena_bytes)) pick = i;
+        if (pick < g_pool.size()) { HostCtx *c = g_pool[pick]; g_pool.erase(g_pool.begin() + (long)pick); *e = hipSetDevice(device); return c; }
     }
     if ((*e = hipSetDevice(device)) != hipSuccess) return nullptr;
     HostCtx *c = new HostCtx();
@@ -2101,11 +2103,19 @@ static HostCtx *ctx_acquire(int device, hipError_t *e)
     if ((*e = hipHostMalloc((void **)&c->pinned, kStageBytes, hipHostMallocDefault)) != hipSuccess) { delete c; return nullptr; }
     return c;
 }
-// back to the pool: a large arena is handed back to the device first (one big sweep must not keep tens of GB away from
-// the rest of the process), and a device keeps at most kPoolPerDevice idle contexts
+// back to the pool: a device keeps at most kPoolPerDevice idle contexts, and only ONE of them an arena above kArenaKeepBytes (the
+// others hand theirs back to the device first; epi_host_pool_release frees everything).  Until round 6 every large arena was
+// returned at once -- but hipFree takes ~30 ms per GiB on these boxes (24 GiB: 730 ms; hipMalloc 0.4 ms) and the next hipMalloc
+// sometimes waits behind it for seconds: the headline sweep's host-pointer call took 16 ms or 0.7-6 s, the 9 375-chain shard with all
+// outputs 118 or 200 ms, depending on whether the previous call's arena was still being returned (profiles/r06/host_calls.json).
 static void ctx_release(HostCtx *c)
 {
-    if (c->arena_bytes > kArenaKeepBytes && !c->tuned) {
+    bool big_kept = false;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (HostCtx *o : g_pool) big_kept = big_kept || (o->device == c->device && o->arena_bytes > kArenaKeepBytes);
+    }
+    if (c->arena_bytes > kArenaKeepBytes && !c->tuned && big_kept) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipFree(c->arena);
         c->arena = nullptr; c->arena_bytes = 0;
