@@ -479,7 +479,7 @@ def main():
                          "kernel_ms": ms[dom], "algorithmic_bytes_per_launch": dom_bytes,
                          "limiter": {"ekf_fwd": "HBM writes: 32.4 GB at the box's fill rate; a lone wave per SIMD issues 73 % of the time (profiles/r06/valu_summary.json)",
                                      "eks_pinv": "fp64 VALU issue (SIMD VALU busy 82 % of the kernel's duration, three waves per SIMD) on top of 13.5 GB of traffic; profiles/r06/valu_summary.json",
-                                     "eks_bwd": "instruction issue of a lone wave per SIMD in two rounds (a wave issues 66 % of its cycles, waits for memory 12 %); HBM second (32 GB at 4.8 TB/s); profiles/r06/valu_summary.json"}[dom]},
+                                     "eks_bwd": "instruction issue of a lone wave per SIMD in two rounds (a wave issues 70 % of its cycles, waits for memory 9 %) and HBM (32.6 GB at 4.9-5.1 TB/s, the first round at the box's copy rate); profiles/r06/valu_summary.json, traffic_summary.json"}[dom]},
             "kernels": {**{k + "_ms": v for k, v in ms.items()},
                         **{k + "_GBs": alg[k] * steps_per_pass / (ms[k] * 1e-3) / 1e9 for k in ms},
                         "whole_step_algorithmic_bytes": step_bytes, "whole_step_GBs": step_gbs,
